@@ -1,0 +1,328 @@
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference implementation.
+
+Run in the build container only (needs /root/reference; it does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+Outputs are small .npz files of plain arrays (inputs + the reference's outputs).  Nothing of the
+reference's source travels.  IDs follow SURVEY.md Appendix C (G1..G10).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("RENI_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# the reference's utils module imports gdown / torchvision at module top; neither is installed
+# and neither is used by get_directions / get_sineweight -> stub the names.
+for name in ("gdown", "torchvision", "torchvision.transforms"):
+    if name not in sys.modules:
+        sys.modules[name] = types.ModuleType(name)
+sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+sys.path.insert(0, REF)
+
+from src.models import RENI as ref  # noqa: E402
+from src.utils import loss_functions as ref_loss  # noqa: E402
+from src.utils import utils as ref_utils  # noqa: E402
+from PIL import Image  # noqa: E402
+
+
+def sd_np(module):
+    return {k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def synth_targets(B, P, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(B, P, 3, generator=g) * 2 - 1
+
+
+# ---------------------------------------------------------------- G1 grids
+def g1():
+    out = {}
+    for W in (32, 64):
+        out[f"dir_{W}"] = ref_utils.get_directions(W).numpy()
+        out[f"sw_{W}"] = ref_utils.get_sineweight(W).numpy()
+    for W in (256, 1024):
+        d = ref_utils.get_directions(W)
+        s = ref_utils.get_sineweight(W)
+        out[f"dir_{W}_head"] = d[0, :64].numpy()
+        out[f"dir_{W}_tail"] = d[0, -64:].numpy()
+        out[f"dir_{W}_sum64"] = d.double().sum((0, 1)).numpy()
+        out[f"sw_{W}_head"] = s[0, :64].numpy()
+        out[f"sw_{W}_tail"] = s[0, -64:].numpy()
+        out[f"sw_{W}_sum64"] = s.double().sum().numpy()
+    save("g1_grids.npz", **out)
+
+
+# ---------------------------------------------------------------- G2 encodings
+def g2():
+    out = {}
+    for tag, (B, nd, P) in {"a": (2, 3, 5), "b": (2, 9, 16)}.items():
+        g = torch.Generator().manual_seed(11)
+        Z = torch.randn(B, nd, 3, generator=g)
+        D = torch.nn.functional.normalize(torch.randn(B, P, 3, generator=g), dim=-1)
+        out[f"Z_{tag}"] = Z.numpy(); out[f"D_{tag}"] = D.numpy()
+        out[f"so2_{tag}"] = ref.SO2InvariantRepresentation(Z, D).numpy()
+        out[f"so3_{tag}"] = ref.SO3InvariantRepresentation(Z, D).numpy()
+        out[f"none_{tag}"] = ref.NoInvariance(Z, D).numpy()
+    save("g2_encodings.npz", **out)
+
+
+# ---------------------------------------------------------------- G3 C1 forward
+def g3():
+    torch.manual_seed(0)
+    m = ref.RENIAutoDecoder(1, 9, "SO2", 64, 3, 3, True, None, 30, 30, False)
+    D = ref_utils.get_directions(64)
+    with torch.no_grad():
+        out = m(0, D)
+    arrs = {"sd." + k: v for k, v in sd_np(m).items()}
+    save("g3_c1_forward.npz", out=out.numpy(), **arrs)
+
+
+# ---------------------------------------------------------------- G4 fwd+bwd training
+def _fwd_bwd(m, Z, D, t, s):
+    for p in m.parameters():
+        p.grad = None
+    Zr = Z.clone().requires_grad_(True)
+    out = m(Zr, D)
+    loss = ref_loss.RENITrainLoss()(out, t, s)
+    loss.backward()
+    return out.detach(), loss.detach(), Zr.grad.detach()
+
+
+def g4():
+    # small: full grads
+    torch.manual_seed(4)
+    m = ref.RENIAutoDecoder(2, 9, "SO2", 64, 3, 3, True, "tanh", 30, 30, False)
+    W = 32
+    D = ref_utils.get_directions(W).repeat(2, 1, 1)
+    s = ref_utils.get_sineweight(W).repeat(2, 1, 1)
+    t = synth_targets(2, D.shape[1], 40)
+    Z = m.Z.detach().clone()
+    out, loss, dZ = _fwd_bwd(m, Z, D, t, s)
+    arrs = {"sd." + k: v for k, v in sd_np(m).items()}
+    arrs.update({"g." + k: p.grad.numpy().copy() for k, p in m.named_parameters() if k != "Z"})
+    save("g4_small.npz", Z=Z.numpy(), target=t.numpy(), out=out.numpy(), loss=loss.numpy(),
+         dZ=dZ.numpy(), W=np.int64(W), **arrs)
+    # other equivariances / head variants at the small size (forward + dZ + grads)
+    for tag, (eq, lll, act) in {"so3": ("SO3", True, "tanh"), "none": ("None", True, None),
+                                "sinehead": ("SO2", False, None)}.items():
+        torch.manual_seed(5)
+        m = ref.RENIAutoDecoder(2, 9, eq, 64, 3, 3, lll, act, 30, 30, False)
+        Z = m.Z.detach().clone()
+        out, loss, dZ = _fwd_bwd(m, Z, D, t, s)
+        arrs = {"sd." + k: v for k, v in sd_np(m).items()}
+        arrs.update({"g." + k: p.grad.numpy().copy() for k, p in m.named_parameters() if k != "Z"})
+        save(f"g4_small_{tag}.npz", Z=Z.numpy(), target=t.numpy(), out=out.numpy(),
+             loss=loss.numpy(), dZ=dZ.numpy(), W=np.int64(W), **arrs)
+    # config-2 shape (ND=36,H=128,L=5), B=2, P=2048: norms + heads only, weights by seed recipe
+    torch.manual_seed(42)
+    m = ref.RENIAutoDecoder(2, 36, "SO2", 128, 5, 3, True, "tanh", 30, 30, False)
+    W = 64
+    D = ref_utils.get_directions(W).repeat(2, 1, 1)
+    s = ref_utils.get_sineweight(W).repeat(2, 1, 1)
+    t = synth_targets(2, D.shape[1], 41)
+    Z = m.Z.detach().clone()
+    out, loss, dZ = _fwd_bwd(m, Z, D, t, s)
+    arrs = {"sd." + k: v.astype(np.float32) for k, v in sd_np(m).items()}
+    for k, p in m.named_parameters():
+        if k == "Z":
+            continue
+        gk = p.grad.numpy()
+        arrs["gn." + k] = np.float64(np.linalg.norm(gk.astype(np.float64)))
+        arrs["gh." + k] = gk.reshape(-1)[:32].copy()
+    save("g4_c2shape.npz", Z=Z.numpy(), target=t.numpy(), out_head=out[:, :256].numpy(),
+         out_sum64=out.double().sum().numpy(), loss=loss.numpy(), dZ=dZ.numpy(), W=np.int64(W), **arrs)
+
+
+# ---------------------------------------------------------------- G5 losses
+def g5():
+    g = torch.Generator().manual_seed(5)
+    o = (torch.rand(2, 64, 3, generator=g) * 2 - 1).requires_grad_(True)
+    t = torch.rand(2, 64, 3, generator=g) * 2 - 1
+    s = torch.rand(2, 64, 3, generator=g)
+    Z = torch.randn(2, 9, 3, generator=g).requires_grad_(True)
+    mu = torch.randn(2, 9, 3, generator=g).requires_grad_(True)
+    lv = (torch.randn(2, 9, 3, generator=g) - 5).requires_grad_(True)
+    res = {"o": o.detach().numpy(), "t": t.numpy(), "s": s.numpy(), "Z": Z.detach().numpy(),
+           "mu": mu.detach().numpy(), "lv": lv.detach().numpy()}
+    v = ref_loss.WeightedMSE(o, t, s); (go,) = torch.autograd.grad(v, o)
+    res["mse"] = v.detach().numpy(); res["mse_go"] = go.numpy()
+    v = ref_loss.WeightedCosineSimilarity(o, t, s); (go,) = torch.autograd.grad(v, o)
+    res["cos"] = v.detach().numpy(); res["cos_go"] = go.numpy()
+    v = ref_loss.KLD(mu, lv, 27); gmu, glv = torch.autograd.grad(v, (mu, lv))
+    res["kld"] = v.detach().numpy(); res["kld_gmu"] = gmu.numpy(); res["kld_glv"] = glv.numpy()
+    tl = ref_loss.RENITestLoss(1e-7, 1e-1)(o, t, s, Z)
+    go, gz = torch.autograd.grad(tl[0], (o, Z))
+    res["test"] = np.array([x.item() for x in tl]); res["test_go"] = go.numpy(); res["test_gz"] = gz.numpy()
+    vl = ref_loss.RENIVADTrainLoss(1e-4, 27)(o, t, s, mu, lv)
+    go, gmu, glv = torch.autograd.grad(vl[0], (o, mu, lv))
+    res["vad"] = np.array([x.item() for x in vl]); res["vad_go"] = go.numpy()
+    res["vad_gmu"] = gmu.numpy(); res["vad_glv"] = glv.numpy()
+    save("g5_losses.npz", **res)
+
+
+# ---------------------------------------------------------------- G6 training-step re-enactment
+def g6():
+    """FIT_DECODER / AutoDecoder steps as RENI_module.py:80-146,168-252 prescribes: permute+view of
+    [B,3,H,W] images, Z = model.Z[idx], model(Z, D), RENITrainLoss, Adam(lr) over all params."""
+    torch.manual_seed(6)
+    N, B, W = 4, 2, 32
+    m = ref.RENIAutoDecoder(N, 9, "SO2", 64, 3, 3, True, "tanh", 30, 30, False)
+    sd0 = sd_np(m)
+    g = torch.Generator().manual_seed(60)
+    imgs_all = torch.rand(N, 3, W // 2, W, generator=g) * 2 - 1
+    D1 = ref_utils.get_directions(W); S1 = ref_utils.get_sineweight(W)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    crit = ref_loss.RENITrainLoss()
+    losses = []
+    batches = [[0, 1], [2, 3], [0, 1], [2, 3], [0, 1]]
+    for idx in batches:
+        idx_t = torch.tensor(idx)
+        imgs = imgs_all[idx_t]
+        bs = imgs.shape[0]
+        t = imgs.permute(0, 2, 3, 1).reshape(bs, -1, 3)
+        D = D1.repeat(bs, 1, 1); S = S1.repeat(bs, 1, 1)
+        Z = m.Z[idx_t, :, :]
+        out = m(Z, D)
+        loss = crit(out, t, S)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    arrs = {"sd0." + k: v for k, v in sd0.items()}
+    save("g6_train_steps.npz", imgs=imgs_all.numpy(), batches=np.array(batches), losses=np.array(losses),
+         Z_final=m.Z.detach().numpy(), W0_final=m.net[0].linear.weight.detach().numpy(),
+         Wout_final=m.net[4].weight.detach().numpy(), lr=np.float64(1e-3), W=np.int64(W), **arrs)
+
+
+# ---------------------------------------------------------------- G7 C4 re-enactment (notebook cell 4)
+def g7():
+    """Frozen VAD decoder, latents from zero, Mask-3, RENITestLoss(1e-7,1e-1), Adam lr 1e-1."""
+    torch.manual_seed(42)
+    trained = ref.RENIVariationalAutoDecoder(5, 9, "SO2", 64, 3, 3, True, "tanh", 30, 30, False)
+    ckpt = {"model." + k: v.clone() for k, v in trained.state_dict().items()}
+    N, W = 3, 64
+    m = ref.RENIVariationalAutoDecoder(N, 9, "SO2", 64, 3, 3, True, "tanh", 30, 30, True)
+    m.load_state_dict(ckpt)
+    assert float(m.mu.abs().sum()) == 0.0
+    g = torch.Generator().manual_seed(70)
+    imgs = torch.rand(N, 3, W // 2, W, generator=g) * 2 - 1
+    mask_img = np.array(Image.open(os.path.join(REF, "data/Masks/Mask-3.png")))
+    # torchvision is absent: nearest resize restated (exact 4:1 / 8:1 decimation of a 512x256 mask)
+    hs, ws = mask_img.shape[:2]
+    ri = (np.arange(W // 2) * (hs / (W // 2))).astype(np.int64)
+    ci = (np.arange(W) * (ws / W)).astype(np.int64)
+    mask = torch.from_numpy(mask_img[ri][:, ci, :3].astype(np.float32) / 255.0).reshape(1, -1, 3)
+    D1 = ref_utils.get_directions(W); S1 = ref_utils.get_sineweight(W) * mask
+    opt = torch.optim.Adam(m.parameters(), lr=1e-1)
+    crit = ref_loss.RENITestLoss(alpha=1e-7, beta=1e-1)
+    terms = []
+    idx = torch.arange(N)
+    t = imgs.permute(0, 2, 3, 1).reshape(N, -1, 3)
+    first_grad = None
+    for _ in range(10):
+        D = D1.repeat(N, 1, 1); S = S1.repeat(N, 1, 1)
+        Z = m.mu[idx, :, :]
+        out = m(Z, D)
+        opt.zero_grad()
+        tl = crit(out, t, S, Z)
+        tl[0].backward()
+        if first_grad is None:
+            first_grad = m.mu.grad.detach().clone().numpy()
+        opt.step()
+        terms.append([x.item() for x in tl])
+    arrs = {"ckpt." + k: v.numpy() for k, v in ckpt.items() if ".net." in k or k.startswith("model.net")}
+    save("g7_latent_opt.npz", imgs=imgs.numpy(), mask=mask.numpy(), mask_src=mask_img[..., 0].astype(np.uint8),
+         terms=np.array(terms), mu_final=m.mu.detach().numpy(), mu_grad0=first_grad,
+         W=np.int64(W), **arrs)
+
+
+# ---------------------------------------------------------------- G8 VAD
+def g8():
+    torch.manual_seed(8)
+    m = ref.RENIVariationalAutoDecoder(3, 9, "SO2", 64, 3, 3, True, "tanh", 30, 30, False)
+    idx = torch.tensor([2, 0])
+    torch.manual_seed(80)
+    Z, mu, lv = m.sample_latent(idx)
+    torch.manual_seed(80)
+    eps = torch.randn(2, 9, 3)
+    W = 32
+    D = ref_utils.get_directions(W).repeat(2, 1, 1); S = ref_utils.get_sineweight(W).repeat(2, 1, 1)
+    t = synth_targets(2, D.shape[1], 81)
+    out = m(Z, D)
+    vl = ref_loss.RENIVADTrainLoss(1e-4, 27)(out, t, S, mu, lv)
+    vl[0].backward()
+    arrs = {"sd." + k: v for k, v in sd_np(m).items()}
+    save("g8_vad.npz", idx=idx.numpy(), eps=eps.numpy(), Z=Z.detach().numpy(), target=t.numpy(),
+         terms=np.array([x.item() for x in vl]), g_mu=m.mu.grad.numpy(), g_lv=m.log_var.grad.numpy(),
+         g_W0=m.net[0].linear.weight.grad.numpy(), W=np.int64(W), **arrs)
+
+
+# ---------------------------------------------------------------- G9 API
+def g9():
+    out = {}
+    for mt, cls in (("AD", ref.RENIAutoDecoder), ("VAD", ref.RENIVariationalAutoDecoder)):
+        for eq in ("SO2", "SO3", "None"):
+            torch.manual_seed(9)
+            m = cls(3, 9, eq, 64, 3, 3, True, "tanh", 30, 30, False)
+            sd = m.state_dict()
+            out[f"keys_{mt}_{eq}"] = np.array(list(sd.keys()))
+            out[f"shapes_{mt}_{eq}"] = np.array([str(tuple(v.shape)) for v in sd.values()])
+            out[f"infeat_{mt}_{eq}"] = np.int64(m.in_features)
+    torch.manual_seed(9)
+    m = ref.RENIAutoDecoder(3, 9, "SO2", 64, 3, 3, True, "tanh", 30, 30, False)
+    D = ref_utils.get_directions(16)
+    with torch.no_grad():
+        out["disp_int"] = m(1, D).numpy()
+        out["disp_list"] = m([0, 2], D.repeat(2, 1, 1)).numpy()
+        out["disp_idx"] = m(torch.tensor([2, 1]), D.repeat(2, 1, 1)).numpy()
+        out["disp_lat"] = m(m.Z[[1]], D).numpy()
+    for k, v in sd_np(m).items():
+        out["sd." + k] = v
+    save("g9_api.npz", **out)
+
+
+# ---------------------------------------------------------------- G10 equivariance
+def g10():
+    W = 64
+    D = ref_utils.get_directions(W)
+    th = 0.7
+    Ry = torch.tensor([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], dtype=torch.float32)
+    torch.manual_seed(7)
+    Q, _ = torch.linalg.qr(torch.randn(3, 3))
+    if torch.linalg.det(Q) < 0:
+        Q[:, 0] = -Q[:, 0]
+    out = {"Ry": Ry.numpy(), "R3": Q.numpy()}
+    for eq, R in (("SO2", Ry), ("SO3", Q)):
+        torch.manual_seed(10)
+        m = ref.RENIAutoDecoder(1, 49, eq, 128, 5, 3, True, "tanh", 30, 30, False)
+        with torch.no_grad():
+            Z = m.Z[[0]]
+            a = m(Z, D)
+            b = m(Z @ R.T, D @ R.T)
+        out[f"resid_{eq}"] = np.float64((a - b).abs().max())
+        out[f"Z_{eq}"] = Z.numpy()
+        out[f"out_{eq}_head"] = a[0, :128].numpy()
+        out[f"out_{eq}_sum64"] = a.double().sum().numpy()
+        for k, v in sd_np(m).items():
+            if k != "Z":
+                out[f"sd_{eq}." + k] = v.astype(np.float16) if False else v
+    save("g10_equivariance.npz", **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    for w in which:
+        globals()[w]()
