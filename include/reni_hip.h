@@ -1,0 +1,141 @@
+/* reni_hip.h -- C ABI of libreni_hip.so: the MI355X (gfx950) RENI forward / training hot path.
+ *
+ * This is the drop-in boundary underneath the reference's nn.Module surface.  The reference
+ * (JADGardner/RENI) has no FFI of its own; the seam it offers is the call
+ *     model_output = self.model(Z, directions)            src/lightning/RENI_module.py:105 (training)
+ *                                                          src/lightning/RENI_module.py:78  (inference)
+ * into src/models/RENI.py (SO2/SO3/None invariant encoding :23-60, SineLayer :63-87, decoder
+ * :132-178) plus the loss of src/utils/loss_functions.py:6-71 and the autograd backward of both.
+ * Each entry point below names the reference code it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer on the current HIP device unless it says "host";
+ *  - all tensors are fp32, row-major, contiguous unless a stride argument says otherwise;
+ *  - `stream` is a hipStream_t passed as void* (0 = the null stream);
+ *  - every function returns 0 on success or a negative RENI_E* code; the message of the last
+ *    failure on the calling thread is available from reni_last_error();
+ *  - the library allocates nothing per call: the caller owns params, gradients, I/O and the
+ *    workspace (size from reni_workspace_bytes); the plan is immutable after creation.
+ *
+ * Flat parameter layout (`params`, `dparams`): the decoder's state_dict in the reference's own
+ * order (src/models/RENI.py:132-178): net.0.linear.weight [H,F_in], net.0.linear.bias [H],
+ * net.l.linear.weight [H,H], net.l.linear.bias [H] for l = 1..L, then the head weight [3,H] and
+ * bias [3].  reni_param_count() gives the total.
+ */
+#ifndef RENI_HIP_H
+#define RENI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RENI_OK 0
+#define RENI_EINVAL (-1)       /* bad argument / unsupported shape */
+#define RENI_EWORKSPACE (-2)   /* workspace too small */
+#define RENI_EHIP (-3)         /* a HIP runtime call failed */
+#define RENI_EUNSUPPORTED (-4) /* configuration not supported by the compiled kernels */
+
+/* reni_desc.equivariance : which invariant encoding (src/models/RENI.py:118-126) */
+#define RENI_EQ_NONE 0
+#define RENI_EQ_SO2 1
+#define RENI_EQ_SO3 2
+/* reni_desc.output_activation (src/models/RENI.py:173-176) */
+#define RENI_ACT_NONE 0
+#define RENI_ACT_TANH 1
+#define RENI_ACT_EXP 2
+/* reni_desc.dtype : arithmetic of the dense layers */
+#define RENI_F32 0  /* fp32 MFMA (v_mfma_f32_32x32x2_f32), precise sin/cos: bit-for-bit an fmaf chain */
+#define RENI_BF16 1 /* bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate, fp32 sin argument    */
+
+/* loss_kind for reni_forward_loss_backward */
+#define RENI_LOSS_MSE 0  /* RENITrainLoss      = WeightedMSE                  loss_functions.py:6-13,39-45 */
+#define RENI_LOSS_TEST 1 /* RENITestLoss       = MSE + alpha*|Z|^2 + beta*WeightedCosine  :25-32,60-71     */
+
+/* flags */
+#define RENI_NEED_DW 1u /* produce decoder gradients (dparams)                      */
+#define RENI_NEED_DZ 2u /* produce latent gradients (dZ)                            */
+
+typedef struct reni_plan reni_plan;
+
+typedef struct reni_desc {
+  int32_t equivariance;      /* RENI_EQ_*                                   RENI.py:118-126 */
+  int32_t ndims;             /* latent rows ND (Z is [ND,3])                RENI.py:94      */
+  int32_t hidden_features;   /* H: 32, 64 or 128                            RENI.py:96      */
+  int32_t hidden_layers;     /* L: number of hidden SineLayers after the first (L+1 sine layers) RENI.py:143 */
+  int32_t out_features;      /* must be 3                                    RENI.py:98      */
+  int32_t last_layer_linear; /* 1: linear head, 0: sine head                RENI.py:153-171 */
+  int32_t output_activation; /* RENI_ACT_*                                  RENI.py:173-176 */
+  float first_omega_0;       /*                                             RENI.py:139     */
+  float hidden_omega_0;      /*                                             RENI.py:149     */
+  int32_t dtype;             /* RENI_F32 | RENI_BF16 */
+} reni_desc;
+
+/* Message of the last error raised on this thread ("" if none). */
+const char* reni_last_error(void);
+
+/* Replaces the constructor of RENIAutoDecoder / RENIVariationalAutoDecoder as far as the decoder
+ * is concerned (src/models/RENI.py:91-178): validates the hyper-parameters, selects kernels. */
+int reni_plan_create(const reni_desc* desc, reni_plan** out_plan);
+void reni_plan_destroy(reni_plan* plan);
+
+/* Number of fp32 elements of the flat decoder parameter buffer; F_in via reni_in_features. */
+int64_t reni_param_count(const reni_plan* plan);
+int32_t reni_in_features(const reni_plan* plan);
+
+/* Bytes of workspace the calls below need for (B images) x (P directions).  `flags` as passed
+ * to the call (0 for reni_forward). */
+size_t reni_workspace_bytes(const reni_plan* plan, int64_t B, int64_t P, uint32_t flags);
+
+/* out[B,P,3] = model(Z, D) under no_grad -- replaces InvariantRepresentation + self.net(x)
+ * (src/models/RENI.py:225-233) as called from RENI.forward (src/lightning/RENI_module.py:75-78).
+ * Z [B,ND,3]; D [B,P,3] with `d_batch_stride` elements between images (0 = one shared grid
+ * [P,3], which is what RENI_module.py:77 materialises with .repeat). */
+int reni_forward(const reni_plan* plan, int64_t B, int64_t P, const float* Z, const float* D,
+                 int64_t d_batch_stride, const float* params, float* out, void* ws,
+                 size_t ws_bytes, void* stream);
+
+/* Fused model(Z,D) -> loss -> backward: replaces RENI_module.py:105 + the criterion call
+ * (:117 / :126-128) + loss.backward() for the decoder and latents.
+ *   target  : element (b,p,c) at target[b*tgt_strides[0] + p*tgt_strides[1] + c*tgt_strides[2]]
+ *             (accepts the channel-planar view of RENI_module.py:83-84 without a copy);
+ *   weight  : sineweight (x mask), element (b,p,c) at weight[b*w_strides[0] + ...]; a stride of 0
+ *             broadcasts (the reference .repeat's one [1,P,3] grid, RENI_module.py:90-94);
+ *   loss_kind, alpha, beta : RENI_LOSS_*; alpha/beta only for RENI_LOSS_TEST;
+ *   out     : optional [B,P,3] model output (NULL to skip the store);
+ *   loss_terms[4] : (loss, mse, prior, cosine) summed over the batch as the reference does;
+ *   dZ [B,ND,3]   : d loss / d Z   (written when flags & RENI_NEED_DZ);
+ *   dparams       : flat decoder gradient, OVERWRITTEN (written when flags & RENI_NEED_DW). */
+int reni_forward_loss_backward(const reni_plan* plan, int64_t B, int64_t P, const float* Z,
+                               const float* D, int64_t d_batch_stride, const float* params,
+                               const float* target, const int64_t tgt_strides[3],
+                               const float* weight, const int64_t w_strides[3], int32_t loss_kind,
+                               float alpha, float beta, uint32_t flags, float* out,
+                               float* loss_terms, float* dZ, float* dparams, void* ws,
+                               size_t ws_bytes, void* stream);
+
+/* Backward for an arbitrary upstream gradient dout[B,P,3] (generic autograd use of
+ * model(Z,D)); the forward is recomputed inside the same fused kernel. */
+int reni_backward(const reni_plan* plan, int64_t B, int64_t P, const float* Z, const float* D,
+                  int64_t d_batch_stride, const float* params, const float* dout, uint32_t flags,
+                  float* dZ, float* dparams, void* ws, size_t ws_bytes, void* stream);
+
+/* torch.optim.Adam(lr, betas=(b1,b2), eps) step on a flat buffer (RENI_module.py:192: the
+ * reference always uses the default betas (0.9, 0.999), eps 1e-8).  `step` is the 1-based step
+ * count; g is multiplied by grad_scale first (1/world_size after a sum all-reduce). */
+int reni_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                   float b2, float eps, int64_t step, float grad_scale, void* stream);
+
+/* Self-test of the MFMA fragment layouts the kernels rely on; out (host pointer) receives the
+ * number of mismatching elements per probe (0 = layout as assumed). */
+int reni_selftest_layouts(int32_t* out_host_mismatch, int32_t n_probes);
+
+/* Launch geometry chosen for (B,P): workgroups, threads, dynamic LDS bytes (diagnostics). */
+int reni_launch_info(const reni_plan* plan, int64_t B, int64_t P, int32_t* info4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RENI_HIP_H */

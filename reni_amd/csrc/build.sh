@@ -1,0 +1,6 @@
+#!/bin/bash
+# Build libreni_hip.so for gfx950 (cross-compiles without a GPU).  Usage: build.sh [extra hipcc flags]
+set -e
+cd "$(dirname "$0")"
+mkdir -p ../lib
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I../../include reni_kernels.hip -o ../lib/libreni_hip.so "$@"

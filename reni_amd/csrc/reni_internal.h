@@ -1,0 +1,78 @@
+// reni_internal.h -- kernel argument blocks shared by reni_kernels.hip and reni_capi.inc
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace reni {
+
+constexpr int MAX_LAYERS = 15;  // hidden_layers <= MAX_LAYERS - 1
+
+struct MainArgs {
+  // geometry
+  int B, P, tiles_per_image, n_tiles;
+  int L, last_linear, act, loss_kind, need_dw;
+  float w_first, w_hidden, beta;
+  // inputs
+  const float* Z;
+  const float* D;
+  long long d_bstride;
+  const float* Apre;  // [B][H][8] per-image affine map of the first layer
+  const char* wimg;   // packed weight images
+  unsigned fwd_off[MAX_LAYERS + 2];  // byte offsets into wimg, index 1..L hidden, L+1 head
+  unsigned bwd_off[MAX_LAYERS + 2];
+  const float* target;
+  long long ts0, ts1, ts2;
+  const float* weight;
+  long long ws0, ws1, ws2;
+  const float* dout;
+  const float* stats;  // [B][16] cosine-term coefficients
+  // outputs / scratch
+  float* out;
+  char* stash;
+  size_t stash_per_wg;
+  float* dwp;  // per-workgroup decoder-gradient partials, flat parameter layout
+  size_t dwp_per_wg;
+  unsigned p_off_w[MAX_LAYERS + 2];  // float offsets of W_l / b_l in the flat layout
+  unsigned p_off_b[MAX_LAYERS + 2];
+  float* dA_part;    // [n_tiles][H][16]
+  float* loss_part;  // [n_tiles][4][16]
+};
+
+struct PrepArgs {
+  const float* Z;
+  const float* W0;
+  const float* b0;
+  float* xconst;  // [B][F_in]
+  float* A;       // [B][H][8]
+  int eq, nd, F_in, H;
+};
+
+struct PackDesc {
+  unsigned src;       // float offset of the weight matrix in params
+  unsigned bias_src;  // float offset of its bias
+  unsigned dst;       // byte offset in wimg
+  int M, K;           // logical matrix [M][K] row-major
+  int transposed;     // 0: image rows = M rows, k = K cols ; 1: image rows = K cols, k = M rows
+  int nrb, nks;       // image geometry
+  int bias_n, bias_n_pad;
+};
+
+struct PackArgs {
+  const float* params;
+  char* wimg;
+  PackDesc d[2 * (MAX_LAYERS + 1)];
+};
+
+struct TailArgs {
+  const float* dA;  // [B][H][8]
+  const float* W0;
+  const float* Z;
+  const float* xconst;
+  float* dZ;
+  float* dW0;
+  float* db0;
+  float alpha2;
+  int eq, nd, F_in, H, B;
+};
+
+}  // namespace reni

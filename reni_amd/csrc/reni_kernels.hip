@@ -1,0 +1,933 @@
+// reni_kernels.hip -- hand-written gfx950 (CDNA4) kernels for the RENI forward / training hot path.
+//
+// What is computed (reference: /root/reference/src/models/RENI.py:23-60 invariant encodings,
+// :63-87 SineLayer, :132-178 decoder; src/utils/loss_functions.py:6-71 losses) and how it is
+// re-factored for the GPU is described in DESIGN.md.  Short version:
+//
+//   * Every column of the reference's concatenated MLP input is either constant per image
+//     (Gram entries, Z_y, vec(Z)) or linear in the direction d (inner products d.Z^T, |d_xz|,
+//     d_y).  The first SineLayer therefore collapses to a per-image affine map
+//         a0 = A_b . (dx, dy, dz, r, 1),   A_b in R^{H x 5}   (k_prep_image)
+//     and its backward to a per-image H x 5 reduction dA_b (fused kernel) followed by tiny
+//     per-image tails (k_tail_dz, k_tail_dw0).
+//   * The dense part runs on MFMA with activations laid out [feature][sample]: the weights are
+//     the A operand (read from LDS), the activations the B operand, so the accumulator of layer l
+//     (lane = sample, registers = features) IS the B operand of layer l+1 after sin() -- the
+//     chain never leaves registers.
+//   * One 256-thread workgroup = 4 waves x 32 samples = a 128-sample tile.  Forward stashes the
+//     sine arguments of every layer (u16 phase for bf16, fp32 pre-activation for fp32) to a
+//     per-workgroup scratch ring that stays cache resident; backward replays them in reverse.
+//   * Weight gradients are MFMA GEMMs with K = samples: gradients/activations are transposed
+//     through LDS once per layer and tile; per-workgroup partial sums are reduced by
+//     k_reduce_partials in a fixed order (deterministic, no float atomics).
+//
+// gfx950 only.  No portability layer.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "reni_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define DEV __device__ __forceinline__
+
+namespace reni {
+
+// Row (within a 32-row block) held by accumulator register r of a 32x32 MFMA result in a lane
+// of the upper (hi=1) or lower (hi=0) half-wave.  (cdna_hip_programming.md section 3.)
+DEV constexpr int rowmap(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ------------------------------------------------------------------------------------------
+// precision policies
+// ------------------------------------------------------------------------------------------
+struct PolF32 {
+  static constexpr bool BF = false;
+  static constexpr int FRAGB = 4;        // bytes per lane of one A/B fragment
+  static constexpr int KF = 2;           // features contracted per MFMA (k-step)
+  static constexpr int TS = 2;           // samples contracted per MFMA in the dW GEMMs
+  static constexpr int ROUND_WAVES = 1;  // waves whose samples share one dW transposition round
+  static constexpr int WPS = 1;          // waves per SIMD to compile for
+  static constexpr int HEAD_BWD_KS = 3;  // k-steps that cover the 3 real head outputs
+  static constexpr int STASH_CH_PER_RB = 4;  // 16-byte chunks per lane per 32-feature block
+  using Frag = float;
+  static DEV f32x16 mfma(Frag a, Frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+struct PolBF16 {
+  static constexpr bool BF = true;
+  static constexpr int FRAGB = 16;
+  static constexpr int KF = 16;
+  static constexpr int TS = 16;
+  static constexpr int ROUND_WAVES = 4;
+  static constexpr int WPS = 2;
+  static constexpr int HEAD_BWD_KS = 1;
+  static constexpr int STASH_CH_PER_RB = 2;
+  using Frag = bf16x8;
+  static DEV f32x16 mfma(Frag a, Frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// feature index (within the layer input) that k-slot (ks, hi, e) of a fragment stands for.
+// It is the order in which a D-layout register file enumerates features, so that accumulators
+// can be fed back as B operands without any data movement.
+template <class Pol>
+__host__ __device__ constexpr int kfeat(int ks, int hi, int e) {
+  if (Pol::BF) return 16 * ks + (e & 3) + 8 * (e >> 2) + 4 * hi;
+  return 32 * (ks >> 4) + ((ks & 15) & 3) + 8 * ((ks & 15) >> 2) + 4 * hi;
+}
+
+// LDS geometry ------------------------------------------------------------------------------
+template <class Pol, int H>
+struct Geo {
+  static constexpr int NRB = H / 32;
+  static constexpr int NKS = H / Pol::KF;                       // k-steps of an H-wide contraction
+  static constexpr int IMG_HID = NRB * NKS * 64 * Pol::FRAGB;   // hidden layer image (fwd or bwd)
+  static constexpr int IMG_HF = 1 * NKS * 64 * Pol::FRAGB;      // head forward image
+  static constexpr int IMG_HB = NRB * Pol::HEAD_BWD_KS * 64 * Pol::FRAGB;  // head backward image
+  static constexpr int BIAS_HID = H * 4;
+  static constexpr int BIAS_HEAD = 32 * 4;
+  static constexpr int ROUND_SAMPLES = 32 * Pol::ROUND_WAVES;
+  // transposition images: bf16 [feature][sample] rows padded by 16 B; fp32 [sample][feature+1]
+  static constexpr int T_ROWB = ROUND_SAMPLES * 2 + 16;
+  static constexpr int T_BYTES = Pol::BF ? (H * T_ROWB) : (ROUND_SAMPLES * (H + 1) * 4);
+  static constexpr int T_BYTES_AL = (T_BYTES + 255) & ~255;
+  static constexpr int WB_RAW = (IMG_HID + BIAS_HID) > T_BYTES_AL ? (IMG_HID + BIAS_HID) : T_BYTES_AL;
+  static constexpr int WB_BYTES = (WB_RAW + 255) & ~255;
+  static constexpr int LDS_BYTES = WB_BYTES + T_BYTES_AL;
+  static constexpr int STASH_CH = NRB * Pol::STASH_CH_PER_RB;   // 16-B chunks per lane per layer
+  static constexpr int STASH_LAYER_BYTES = STASH_CH * 256 * 16;
+};
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+DEV float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+
+
+// sin and cos of an fp32 argument, ~1 ulp for |x| < 1e4: three-term Cody-Waite reduction by pi/2
+// with FMAs, then degree-9 / degree-8 minimax polynomials on [-pi/4, pi/4].  Used by the fp32
+// (parity-grade) kernels instead of the library sinf/cosf, whose huge-argument slow path costs
+// scratch memory and a loop.
+DEV void sincos_f32(float x, float& s, float& c) {
+  const float kf = rintf(x * 0.63661977236758134f);
+  float r = __builtin_fmaf(-kf, 1.57079637050628662109375f, x);
+  r = __builtin_fmaf(-kf, -4.37113900018624283e-8f, r);
+  r = __builtin_fmaf(-kf, -1.71512449e-15f, r);
+  const float r2 = r * r;
+  float ps = __builtin_fmaf(r2, 2.7557314297e-06f, -1.9841270114e-04f);
+  ps = __builtin_fmaf(ps, r2, 8.3333337680e-03f);
+  ps = __builtin_fmaf(ps, r2, -1.6666667163e-01f);
+  const float sr = __builtin_fmaf(ps * r2, r, r);
+  float pc = __builtin_fmaf(r2, -2.7557314297e-07f, 2.4801587642e-05f);
+  pc = __builtin_fmaf(pc, r2, -1.3888889225e-03f);
+  pc = __builtin_fmaf(pc, r2, 4.1666667908e-02f);
+  const float cr = __builtin_fmaf(pc * r2, r2, __builtin_fmaf(-0.5f, r2, 1.0f));
+  const int q = (int)kf;
+  const float s0 = (q & 1) ? cr : sr;
+  const float c0 = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
+DEV float sin_f32(float x) { float s, c; sincos_f32(x, s, c); return s; }
+DEV float cos_f32(float x) { float s, c; sincos_f32(x, s, c); return c; }
+
+DEV void stage_to_lds(char* dst, const char* src, int bytes, int tid) {
+  for (int o = tid * 16; o < bytes; o += 256 * 16) *(u32x4*)(dst + o) = *(const u32x4*)(src + o);
+}
+
+template <class Pol, int NRB_OUT>
+DEV void acc_init_bias(f32x16 (&acc)[NRB_OUT], const float* bias_lds, int hi) {
+#pragma unroll
+  for (int rb = 0; rb < NRB_OUT; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rb][r] = bias_lds[32 * rb + rowmap(r, hi)];
+}
+
+template <int NRB_OUT>
+DEV void acc_zero(f32x16 (&acc)[NRB_OUT]) {
+#pragma unroll
+  for (int rb = 0; rb < NRB_OUT; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+}
+
+// D[32*rbo.., sample] += sum_k Wimg[rbo][k] * vin[k]  for the wave's 32 samples.
+// vin is a D-layout register file (lane = sample, register = feature).
+template <class Pol, int NRB_OUT, int NRB_IN, int NKS_USE>
+DEV void gemm_lds(const char* wb, const float (&vin)[NRB_IN][16], f32x16 (&acc)[NRB_OUT], int lane) {
+  if constexpr (Pol::BF) {
+    bf16x8 bop[NKS_USE];
+#pragma unroll
+    for (int ks = 0; ks < NKS_USE; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bop[ks][e] = (__bf16)vin[ks >> 1][(ks & 1) * 8 + e];
+#pragma unroll
+    for (int ks = 0; ks < NKS_USE; ++ks)
+#pragma unroll
+      for (int rbo = 0; rbo < NRB_OUT; ++rbo) {
+        bf16x8 a = *(const bf16x8*)(wb + ((rbo * NKS_USE + ks) * 64 + lane) * 16);
+        acc[rbo] = PolBF16::mfma(a, bop[ks], acc[rbo]);
+      }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < NKS_USE; ++ks)
+#pragma unroll
+      for (int rbo = 0; rbo < NRB_OUT; ++rbo) {
+        float a = *(const float*)(wb + ((rbo * NKS_USE + ks) * 64 + lane) * 4);
+        acc[rbo] = PolF32::mfma(a, vin[ks >> 4][ks & 15], acc[rbo]);
+      }
+  }
+}
+
+// v: pre-activation a (in)  ->  h = sin(omega a) (out); the sine argument is stashed for backward.
+template <class Pol, int NRB, bool STASH>
+DEV void act_forward(float (&v)[NRB][16], float omega, char* stash_layer, int tid) {
+  if constexpr (Pol::BF) {
+    const float sc = omega * 0.15915494309189535f;  // argument in revolutions
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      unsigned q[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float th = __builtin_amdgcn_fractf(v[rb][r] * sc);
+        q[r] = ((unsigned)(th * 65536.f + 0.5f)) & 0xffffu;
+        v[rb][r] = __builtin_amdgcn_sinf(th);
+      }
+      if constexpr (STASH) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          u32x4 w;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) w[d] = q[8 * c + 2 * d] | (q[8 * c + 2 * d + 1] << 16);
+          *(u32x4*)(stash_layer + ((rb * 2 + c) * 256 + tid) * 16) = w;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      if constexpr (STASH) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          f32x4 w = {v[rb][4 * c], v[rb][4 * c + 1], v[rb][4 * c + 2], v[rb][4 * c + 3]};
+          *(f32x4*)(stash_layer + ((rb * 4 + c) * 256 + tid) * 16) = w;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[rb][r] = sin_f32(omega * v[rb][r]);
+    }
+  }
+}
+
+// Reload a layer's stash; WHAT = 0: cos(omega a) * scale * g (in place on g), WHAT = 1: sin(omega a) -> out
+template <class Pol, int NRB, int WHAT>
+DEV void act_replay(float (&x)[NRB][16], const f32x16* g, float omega, float scale,
+                    const char* stash_layer, int tid) {
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) {
+    if constexpr (Pol::BF) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        u32x4 w = *(const u32x4*)(stash_layer + ((rb * 2 + c) * 256 + tid) * 16);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          float t0 = (float)(w[d] & 0xffffu) * (1.f / 65536.f);
+          float t1 = (float)(w[d] >> 16) * (1.f / 65536.f);
+          const int r = 8 * c + 2 * d;
+          if constexpr (WHAT == 0) {
+            x[rb][r] = g[rb][r] * scale * __builtin_amdgcn_cosf(t0);
+            x[rb][r + 1] = g[rb][r + 1] * scale * __builtin_amdgcn_cosf(t1);
+          } else {
+            x[rb][r] = __builtin_amdgcn_sinf(t0);
+            x[rb][r + 1] = __builtin_amdgcn_sinf(t1);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        f32x4 w = *(const f32x4*)(stash_layer + ((rb * 4 + c) * 256 + tid) * 16);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const int r = 4 * c + d;
+          if constexpr (WHAT == 0) x[rb][r] = g[rb][r] * scale * cos_f32(omega * w[d]);
+          else x[rb][r] = sin_f32(omega * w[d]);
+        }
+      }
+    }
+  }
+}
+
+// ---- transposition through LDS for the K = samples GEMMs ------------------------------------
+template <class Pol, int H, int NB>
+DEV void t_write(char* T, const float (&x)[NB][16], int wslot, int hi, int j) {
+  using G = Geo<Pol, H>;
+#pragma unroll
+  for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = 32 * rb + rowmap(r, hi);
+      if constexpr (Pol::BF) {
+        *(__bf16*)(T + f * G::T_ROWB + (wslot * 32 + j) * 2) = (__bf16)x[rb][r];
+      } else {
+        *(float*)(T + (j * (32 * NB + 1) + f) * 4) = x[rb][r];
+      }
+    }
+}
+
+template <class Pol, int H, int NB>
+DEV typename Pol::Frag t_read(const char* T, int blk, int ks, int i, int khi) {
+  using G = Geo<Pol, H>;
+  if constexpr (Pol::BF) {
+    return *(const bf16x8*)(T + (32 * blk + i) * G::T_ROWB + (16 * ks + 8 * khi) * 2);
+  } else {
+    return *(const float*)(T + ((2 * ks + khi) * (32 * NB + 1) + 32 * blk + i) * 4);
+  }
+}
+
+template <class Pol>
+DEV float frag_sum(typename Pol::Frag a) {
+  if constexpr (Pol::BF) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)a[e];
+    return s;
+  } else {
+    return a;
+  }
+}
+
+enum { DW_HIDDEN = 0, DW_HEAD = 1, DW_L0 = 2 };
+
+// dM[row-feature][col-feature] (+)= sum over the tile's 128 samples rows[.][s] * cols[.][s].
+//   DW_HIDDEN: rows = g_a (layer outputs), cols = h_{l-1}; flushed to dW_l [out][in] and db_l
+//   DW_HEAD  : rows = h_L, cols = g_y (3 real);            flushed to dW_out[c][feature], db_out
+//   DW_L0    : rows = g_a0, cols = (x_hi[5], x_lo[4]);     stored to the per-tile dA partial
+template <class Pol, int H, int NBR, int NBC, int KIND>
+DEV void dw_phase(char* TA, char* TB, const float (&rows)[NBR][16], const float (&cols)[NBC][16],
+                  float* dst_w, float* dst_b, int ldw, bool first, int wave, int lane) {
+  using G = Geo<Pol, H>;
+  constexpr int NBLK = NBR * NBC;
+  constexpr int MYB = (NBLK + 3) / 4;
+  constexpr int NROUND = 4 / Pol::ROUND_WAVES;
+  constexpr int NKS_T = G::ROUND_SAMPLES / Pol::TS;
+  const int hi = lane >> 5, j = lane & 31;
+  f32x16 acc[MYB];
+  acc_zero<MYB>(acc);
+  float dbacc = 0.f;
+#pragma unroll 1
+  for (int round = 0; round < NROUND; ++round) {
+    __syncthreads();
+    if (wave / Pol::ROUND_WAVES == round) {
+      t_write<Pol, H, NBR>(TA, rows, wave % Pol::ROUND_WAVES, hi, j);
+      t_write<Pol, H, NBC>(TB, cols, wave % Pol::ROUND_WAVES, hi, j);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < NKS_T; ++ks) {
+#pragma unroll
+      for (int m = 0; m < MYB; ++m) {
+        const int blk = wave + 4 * m;
+        if (blk < NBLK) {
+          const int rbo = blk % NBR, cb = blk / NBR;
+          typename Pol::Frag fa = t_read<Pol, H, NBR>(TA, rbo, ks, j, hi);
+          typename Pol::Frag fb = t_read<Pol, H, NBC>(TB, cb, ks, j, hi);
+          acc[m] = Pol::mfma(fa, fb, acc[m]);
+          if (KIND == DW_HIDDEN && m == 0 && cb == 0) dbacc += frag_sum<Pol>(fa);
+          if (KIND == DW_HEAD && m == 0 && blk == 0) dbacc += frag_sum<Pol>(fb);
+        }
+      }
+    }
+  }
+  // ---- flush
+#pragma unroll
+  for (int m = 0; m < MYB; ++m) {
+    const int blk = wave + 4 * m;
+    if (blk < NBLK) {
+      const int rbo = blk % NBR, cb = blk / NBR;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * rbo + rowmap(r, hi);
+        if constexpr (KIND == DW_HIDDEN) {
+          float* p = dst_w + (size_t)row * ldw + 32 * cb + j;
+          *p = first ? acc[m][r] : (*p + acc[m][r]);
+        } else if constexpr (KIND == DW_HEAD) {
+          if (j < 3) {
+            float* p = dst_w + (size_t)j * ldw + row;
+            *p = first ? acc[m][r] : (*p + acc[m][r]);
+          }
+        } else {
+          if (j < 16) dst_w[(size_t)row * 16 + j] = acc[m][r];
+        }
+      }
+    }
+  }
+  if constexpr (KIND == DW_HIDDEN) {
+    dbacc += __shfl_xor(dbacc, 32, 64);
+    if (wave < NBR && wave < NBLK && hi == 0) {
+      float* p = dst_b + 32 * (wave % NBR) + j;
+      *p = first ? dbacc : (*p + dbacc);
+    }
+  } else if constexpr (KIND == DW_HEAD) {
+    dbacc += __shfl_xor(dbacc, 32, 64);
+    if (wave == 0 && hi == 0 && j < 3) {
+      float* p = dst_b + j;
+      *p = first ? dbacc : (*p + dbacc);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// the fused kernel
+// ------------------------------------------------------------------------------------------
+enum { MODE_FWD = 0, MODE_STATS = 1, MODE_FWD_BWD = 2 };
+
+template <class Pol, int H, int MODE>
+__global__ void __launch_bounds__(256, Pol::WPS) k_reni_main(const MainArgs a) {
+  using G = Geo<Pol, H>;
+  constexpr int NRB = G::NRB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const WB = smem;
+  char* const TA = smem;  // aliases WB: the weight image is dead while a dW phase runs
+  char* const TB = smem + G::WB_BYTES;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, hi = lane >> 5, j = lane & 31;
+  char* const stash = a.stash + (size_t)blockIdx.x * a.stash_per_wg;
+  float* const dwp = a.dwp + (size_t)blockIdx.x * a.dwp_per_wg;
+  const int L = a.L;
+  bool first = true;
+
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int b = tile / a.tiles_per_image;
+    const int p = (tile - b * a.tiles_per_image) * 128 + wave * 32 + j;
+    const bool valid = p < a.P;
+
+    // ---- direction -> x = (dx, dy, dz, r, 1)
+    float x[5];
+    {
+      const float* dp = a.D + (size_t)b * a.d_bstride + (size_t)(valid ? p : 0) * 3;
+      x[0] = dp[0]; x[1] = dp[1]; x[2] = dp[2];
+      x[3] = sqrtf(x[0] * x[0] + x[2] * x[2]);
+      x[4] = 1.f;
+    }
+    float v[NRB][16];
+    // ---- layer 0: a0 = A_b x  (A_b = per-image affine map, k_prep_image)
+    {
+      f32x16 acc[NRB];
+      acc_zero<NRB>(acc);
+      const float* Ab = a.Apre + (size_t)b * H * 8;
+      if constexpr (Pol::BF) {
+        // x = xh + xl, A = Ah + Al (bf16 pairs); A x ~= Ah xh + Al xh + Ah xl in ONE k=16 MFMA
+        __bf16 xh[5], xl[4];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) xh[k] = (__bf16)x[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xl[k] = (__bf16)(x[k] - (float)xh[k]);
+        bf16x8 bop;
+        if (hi == 0) { bop[0] = xh[0]; bop[1] = xh[1]; bop[2] = xh[2]; bop[3] = xh[3]; bop[4] = xh[4]; bop[5] = xh[0]; bop[6] = xh[1]; bop[7] = xh[2]; }
+        else { bop[0] = xh[3]; bop[1] = xh[4]; bop[2] = xl[0]; bop[3] = xl[1]; bop[4] = xl[2]; bop[5] = xl[3]; bop[6] = (__bf16)0.f; bop[7] = (__bf16)0.f; }
+#pragma unroll
+        for (int rbo = 0; rbo < NRB; ++rbo) {
+          const f32x4 lo4 = *(const f32x4*)(Ab + (32 * rbo + j) * 8);
+          const float a4 = Ab[(32 * rbo + j) * 8 + 4];
+          const float A5[5] = {lo4[0], lo4[1], lo4[2], lo4[3], a4};
+          __bf16 Ah[5], Al[5];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) { Ah[k] = (__bf16)A5[k]; Al[k] = (__bf16)(A5[k] - (float)Ah[k]); }
+          bf16x8 aop;
+          if (hi == 0) { aop[0] = Ah[0]; aop[1] = Ah[1]; aop[2] = Ah[2]; aop[3] = Ah[3]; aop[4] = Ah[4]; aop[5] = Al[0]; aop[6] = Al[1]; aop[7] = Al[2]; }
+          else { aop[0] = Al[3]; aop[1] = Al[4]; aop[2] = Ah[0]; aop[3] = Ah[1]; aop[4] = Ah[2]; aop[5] = Ah[3]; aop[6] = (__bf16)0.f; aop[7] = (__bf16)0.f; }
+          acc[rbo] = PolBF16::mfma(aop, bop, acc[rbo]);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const int k = 2 * ks + hi;
+          const float bx = (k == 0) ? x[0] : (k == 1) ? x[1] : (k == 2) ? x[2] : (k == 3) ? x[3] : (k == 4) ? x[4] : 0.f;
+#pragma unroll
+          for (int rbo = 0; rbo < NRB; ++rbo) {
+            const float av = Ab[(32 * rbo + j) * 8 + k];
+            acc[rbo] = PolF32::mfma(av, bx, acc[rbo]);
+          }
+        }
+      }
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[rb][r] = acc[rb][r];
+    }
+    act_forward<Pol, NRB, MODE == MODE_FWD_BWD>(v, a.w_first, stash, tid);
+
+    // ---- hidden layers 1..L
+#pragma unroll 1
+    for (int l = 1; l <= L; ++l) {
+      __syncthreads();
+      stage_to_lds(WB, a.wimg + a.fwd_off[l], G::IMG_HID + G::BIAS_HID, tid);
+      __syncthreads();
+      f32x16 acc[NRB];
+      acc_init_bias<Pol, NRB>(acc, (const float*)(WB + G::IMG_HID), hi);
+      gemm_lds<Pol, NRB, NRB, G::NKS>(WB, v, acc, lane);
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[rb][r] = acc[rb][r];
+      act_forward<Pol, NRB, MODE == MODE_FWD_BWD>(v, a.w_hidden, stash + (size_t)l * G::STASH_LAYER_BYTES, tid);
+    }
+
+    // ---- head: y = W_out h_L + b_out (rows 0..2 of a 32-row block)
+    float y[3], ylin[3], outv[3];
+    {
+      __syncthreads();
+      stage_to_lds(WB, a.wimg + a.fwd_off[L + 1], G::IMG_HF + G::BIAS_HEAD, tid);
+      __syncthreads();
+      f32x16 acc[1];
+      acc_init_bias<Pol, 1>(acc, (const float*)(WB + G::IMG_HF), hi);
+      gemm_lds<Pol, 1, NRB, G::NKS>(WB, v, acc, lane);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        ylin[c] = acc[0][c];
+        y[c] = a.last_linear ? ylin[c] : sin_f32(a.w_hidden * ylin[c]);
+        outv[c] = (a.act == 1) ? tanhf(y[c]) : (a.act == 2) ? expf(y[c]) : y[c];
+      }
+    }
+    const bool owner = valid && (hi == 0);
+    if (a.out != nullptr && owner) {
+      float* op = a.out + ((size_t)b * a.P + p) * 3;
+      op[0] = outv[0]; op[1] = outv[1]; op[2] = outv[2];
+    }
+    if constexpr (MODE == MODE_FWD) continue;
+
+    // ---- loss and d loss / d out
+    float gy[3] = {0.f, 0.f, 0.f};
+    if constexpr (MODE == MODE_STATS) {
+      float s9[9];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float t = owner ? a.target[(size_t)b * a.ts0 + (size_t)p * a.ts1 + (size_t)c * a.ts2] : 0.f;
+        const float o = owner ? outv[c] : 0.f;
+        s9[c] = o * t; s9[3 + c] = o * o; s9[6 + c] = t * t;
+      }
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const float s = wave_sum(s9[q]);
+        if (lane == 0) a.loss_part[((size_t)tile * 4 + wave) * 16 + 1 + q] = s;
+      }
+      continue;
+    } else {
+      float e = 0.f;
+      if (a.loss_kind == 2) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gy[c] = owner ? a.dout[((size_t)b * a.P + p) * 3 + c] : 0.f;
+      } else {
+        const float inv3p = 1.0f / (3.0f * (float)a.P);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (owner) {
+            const float t = a.target[(size_t)b * a.ts0 + (size_t)p * a.ts1 + (size_t)c * a.ts2];
+            const float s = a.weight[(size_t)b * a.ws0 + (size_t)p * a.ws1 + (size_t)c * a.ws2];
+            const float d = outv[c] - t;
+            e += s * d * d;
+            gy[c] = 2.f * s * d * inv3p;
+            if (a.loss_kind == 1) {
+              const float cA = a.stats[(size_t)b * 16 + c], cB = a.stats[(size_t)b * 16 + 4 + c];
+              gy[c] += cA * t - cB * outv[c];
+            }
+          }
+        }
+      }
+      const float es = wave_sum(e);
+      if (lane == 0) a.loss_part[((size_t)tile * 4 + wave) * 16] = es;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (a.act == 1) gy[c] *= (1.f - outv[c] * outv[c]);
+        else if (a.act == 2) gy[c] *= outv[c];
+        if (!a.last_linear) gy[c] *= a.w_hidden * cos_f32(a.w_hidden * ylin[c]);
+        if (!owner) gy[c] = 0.f;
+      }
+    }
+
+    // =============================== backward ===============================
+    float g[NRB][16];  // gradient w.r.t. the current layer's pre-activation, D layout
+    f32x16 acc[NRB];
+    {
+      float gh[1][16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gh[0][r] = (r < 3) ? gy[r] : 0.f;
+      if (a.need_dw)
+        dw_phase<Pol, H, NRB, 1, DW_HEAD>(TA, TB, v, gh, dwp + a.p_off_w[L + 1], dwp + a.p_off_b[L + 1], H, first, wave, lane);
+      __syncthreads();
+      stage_to_lds(WB, a.wimg + a.bwd_off[L + 1], G::IMG_HB, tid);
+      __syncthreads();
+      acc_zero<NRB>(acc);
+      gemm_lds<Pol, NRB, 1, Pol::HEAD_BWD_KS>(WB, gh, acc, lane);
+    }
+#pragma unroll 1
+    for (int l = L; l >= 1; --l) {
+      act_replay<Pol, NRB, 0>(g, acc, a.w_hidden, a.w_hidden, stash + (size_t)l * G::STASH_LAYER_BYTES, tid);
+      if (a.need_dw) {
+        float hp[NRB][16];
+        act_replay<Pol, NRB, 1>(hp, nullptr, (l - 1 == 0) ? a.w_first : a.w_hidden, 0.f,
+                                stash + (size_t)(l - 1) * G::STASH_LAYER_BYTES, tid);
+        dw_phase<Pol, H, NRB, NRB, DW_HIDDEN>(TA, TB, g, hp, dwp + a.p_off_w[l], dwp + a.p_off_b[l], H, first, wave, lane);
+      }
+      __syncthreads();
+      stage_to_lds(WB, a.wimg + a.bwd_off[l], G::IMG_HID, tid);
+      __syncthreads();
+      acc_zero<NRB>(acc);
+      gemm_lds<Pol, NRB, NRB, G::NKS>(WB, g, acc, lane);
+    }
+    act_replay<Pol, NRB, 0>(g, acc, a.w_first, a.w_first, stash, tid);
+    {
+      float xc[1][16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xc[0][r] = 0.f;
+      if (hi == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if constexpr (Pol::BF) {
+            const float xhk = (float)(__bf16)x[k];
+            xc[0][k] = xhk; xc[0][4 + k] = x[k] - xhk;
+          } else {
+            xc[0][k] = x[k];
+          }
+        }
+      } else {
+        xc[0][0] = 1.f;
+      }
+      dw_phase<Pol, H, NRB, 1, DW_L0>(TA, TB, g, xc, a.dA_part + (size_t)tile * H * 16, nullptr, 16, true, wave, lane);
+    }
+    first = false;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// prologue: per-image constant input columns and the affine map A_b
+// ------------------------------------------------------------------------------------------
+// xconst[b][col] = value of input column col if it is constant over the image, else 0
+// A[b][h][0..4] = coefficients of (dx, dy, dz, r, 1)
+__global__ void __launch_bounds__(256) k_prep_image(const PrepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xc = (float*)smem;  // F_in
+  const int b = blockIdx.x, tid = threadIdx.x, nd = a.nd, F = a.F_in;
+  const float* z = a.Z + (size_t)b * nd * 3;
+  for (int col = tid; col < F; col += 256) {
+    float val = 0.f;
+    if (a.eq == 1) {  // SO2: [ip nd | G nd^2 | r | zy nd | dy]
+      const int c1 = col - nd;
+      if (c1 >= 0 && c1 < nd * nd) {
+        const int i = c1 / nd, k = c1 - i * nd;
+        val = z[i * 3] * z[k * 3] + z[i * 3 + 2] * z[k * 3 + 2];
+      } else if (c1 > nd * nd && c1 <= nd * nd + nd) {
+        val = z[(c1 - nd * nd - 1) * 3 + 1];
+      }
+    } else if (a.eq == 2) {  // SO3: [ip nd | G nd^2]
+      const int c1 = col - nd;
+      if (c1 >= 0) {
+        const int i = c1 / nd, k = c1 - i * nd;
+        val = z[i * 3] * z[k * 3] + z[i * 3 + 1] * z[k * 3 + 1] + z[i * 3 + 2] * z[k * 3 + 2];
+      }
+    } else {  // None: [ip nd | vec(Z) 3nd]
+      const int c1 = col - nd;
+      if (c1 >= 0) val = z[c1];
+    }
+    xc[col] = val;
+    a.xconst[(size_t)b * F + col] = val;
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int h = wave; h < a.H; h += 4) {
+    const float* w = a.W0 + (size_t)h * F;
+    float c = 0.f, ux = 0.f, uy = 0.f, uz = 0.f;
+    for (int col = lane; col < F; col += 64) {
+      const float wv = w[col];
+      c += wv * xc[col];
+      if (col < nd) {
+        ux += wv * z[col * 3];
+        uy += wv * z[col * 3 + 1];
+        uz += wv * z[col * 3 + 2];
+      }
+    }
+    c = wave_sum(c); ux = wave_sum(ux); uy = wave_sum(uy); uz = wave_sum(uz);
+    if (lane == 0) {
+      float* o = a.A + ((size_t)b * a.H + h) * 8;
+      if (a.eq == 1) {
+        o[0] = ux; o[1] = w[F - 1]; o[2] = uz; o[3] = w[nd + nd * nd];
+      } else {
+        o[0] = ux; o[1] = uy; o[2] = uz; o[3] = 0.f;
+      }
+      o[4] = c + a.b0[h];
+      o[5] = 0.f; o[6] = 0.f; o[7] = 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight repacking into MFMA fragment order (once per call; the weights change every step)
+// ------------------------------------------------------------------------------------------
+template <class Pol>
+__global__ void __launch_bounds__(256) k_pack(const PackArgs a) {
+  const PackDesc d = a.d[blockIdx.y];
+  const int nfrag_lanes = d.nrb * d.nks * 64;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < nfrag_lanes; t += gridDim.x * 256) {
+    const int lane = t & 63, fr = t >> 6;
+    const int ks = fr % d.nks, rb = fr / d.nks;
+    const int R = 32 * rb + (lane & 31), hi = lane >> 5;
+    if constexpr (Pol::BF) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int Fk = kfeat<Pol>(ks, hi, e);
+        float val = 0.f;
+        if (!d.transposed) { if (R < d.M && Fk < d.K) val = a.params[d.src + (size_t)R * d.K + Fk]; }
+        else { if (Fk < d.M && R < d.K) val = a.params[d.src + (size_t)Fk * d.K + R]; }
+        o[e] = (__bf16)val;
+      }
+      *(bf16x8*)(a.wimg + d.dst + (size_t)t * 16) = o;
+    } else {
+      const int Fk = kfeat<Pol>(ks, hi, 0);
+      float val = 0.f;
+      if (!d.transposed) { if (R < d.M && Fk < d.K) val = a.params[d.src + (size_t)R * d.K + Fk]; }
+      else { if (Fk < d.M && R < d.K) val = a.params[d.src + (size_t)Fk * d.K + R]; }
+      *(float*)(a.wimg + d.dst + (size_t)t * 4) = val;
+    }
+  }
+  if (d.bias_n_pad > 0 && blockIdx.x == 0) {
+    float* bo = (float*)(a.wimg + d.dst + (size_t)nfrag_lanes * Pol::FRAGB);
+    for (int i = threadIdx.x; i < d.bias_n_pad; i += 256) bo[i] = (i < d.bias_n) ? a.params[d.bias_src + i] : 0.f;
+  }
+}
+template __global__ void k_pack<PolF32>(const PackArgs);
+template __global__ void k_pack<PolBF16>(const PackArgs);
+
+// ------------------------------------------------------------------------------------------
+// epilogue kernels (all fixed-order sums: deterministic)
+// ------------------------------------------------------------------------------------------
+// dparams[i] = sum over workgroups of their partial, for i in [lo, n)
+__global__ void __launch_bounds__(256) k_reduce_partials(const float* part, size_t per_wg, int nwg,
+                                                          float* dparams, int lo, int n) {
+  const int i = lo + blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int w = 0; w < nwg; ++w) s += part[(size_t)w * per_wg + i];
+  dparams[i] = s;
+}
+
+// per image: dA[b][h][k] = sum over the image's tiles (x_hi part + x_lo part); mse[b]
+__global__ void __launch_bounds__(256) k_reduce_tiles(const float* dA_part, const float* loss_part,
+                                                      int tiles_per_image, int H, int P, float* dA,
+                                                      float* img_loss, int have_dA) {
+  const int b = blockIdx.x;
+  if (have_dA) {
+    for (int i = threadIdx.x; i < H * 8; i += 256) {
+      const int h = i >> 3, k = i & 7;
+      float s = 0.f;
+      if (k < 5) {
+        for (int t = 0; t < tiles_per_image; ++t) {
+          const float* q = dA_part + ((size_t)(b * tiles_per_image + t) * H + h) * 16;
+          s += q[k] + ((k < 4) ? q[8 + k] : 0.f);
+        }
+      }
+      dA[((size_t)b * H + h) * 8 + k] = s;
+    }
+  }
+  // loss partial sums: 16 slots per (tile, wave); slot 0 = weighted squared error, 1..9 = stats
+  if (threadIdx.x < 16) {
+    float s = 0.f;
+    for (int t = 0; t < tiles_per_image * 4; ++t) s += loss_part[((size_t)b * tiles_per_image * 4 + t) * 16 + threadIdx.x];
+    img_loss[(size_t)b * 16 + threadIdx.x] = s;
+  }
+}
+
+// cosine-term coefficients per (image, channel) from the forward statistics
+// stats[b][c] = cA, stats[b][4+c] = cB, stats[b][8+c] = cosine similarity * pixel-0 weight
+__global__ void k_cos_coeffs(const float* img_loss, const float* weight, long long ws0, long long ws2,
+                             float beta, int B, float* stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 3) return;
+  const int b = i / 3, c = i - 3 * b;
+  const float sot = img_loss[(size_t)b * 16 + 1 + c], soo = img_loss[(size_t)b * 16 + 4 + c], stt = img_loss[(size_t)b * 16 + 7 + c];
+  const float no = sqrtf(soo), nt = sqrtf(stt);
+  const float den = fmaxf(no * nt, 1e-20f);
+  const float cs = sot / den;
+  const float s0 = weight[(size_t)b * ws0 + (size_t)c * ws2];  // weight of pixel 0 (loss_functions.py:29)
+  stats[(size_t)b * 16 + c] = -beta * s0 / (3.f * den);
+  stats[(size_t)b * 16 + 4 + c] = -beta * s0 * cs / (3.f * soo);
+  stats[(size_t)b * 16 + 8 + c] = cs * s0;
+}
+
+// loss_terms = (loss, mse, prior, cosine)
+__global__ void k_finalize_loss(const float* img_loss, const float* stats, const float* Z, int B, int P,
+                                int nz, int has_cos, int has_prior, float alpha, float beta, float* loss_terms) {
+  __shared__ float red[256];
+  float mse = 0.f, cosv = 0.f, prior = 0.f;
+  if (threadIdx.x == 0) {
+    for (int b = 0; b < B; ++b) mse += img_loss[(size_t)b * 16] / (3.f * (float)P);
+    if (has_cos)
+      for (int b = 0; b < B; ++b) {
+        const float m = (stats[(size_t)b * 16 + 8] + stats[(size_t)b * 16 + 9] + stats[(size_t)b * 16 + 10]) / 3.f;
+        cosv += 1.f - m;
+      }
+  }
+  float zz = 0.f;
+  if (has_prior)
+    for (int i = threadIdx.x; i < nz; i += 256) zz += Z[i] * Z[i];
+  red[threadIdx.x] = zz;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    prior = alpha * red[0];
+    cosv *= beta;
+    loss_terms[0] = mse + prior + cosv;
+    loss_terms[1] = mse;
+    loss_terms[2] = prior;
+    loss_terms[3] = cosv;
+  }
+}
+
+// per image: m[col] = W0[:,col]^T g (g = constant-column gradient dA[:,4], or the direction
+// columns for the inner-product block), then assemble dZ
+__global__ void __launch_bounds__(256) k_tail_dz(const TailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int F = a.F_in, nd = a.nd, H = a.H, b = blockIdx.x, tid = threadIdx.x;
+  float* m = (float*)smem;   // F : W0^T g_c
+  float* u = m + F;          // 3*nd : W_ip^T dU (x,y,z components)
+  float* dAs = u + 3 * nd;   // H*8
+  for (int i = tid; i < H * 8; i += 256) dAs[i] = a.dA[(size_t)b * H * 8 + i];
+  __syncthreads();
+  for (int col = tid; col < F; col += 256) {
+    float s = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int h = 0; h < H; ++h) {
+      const float w = a.W0[(size_t)h * F + col];
+      s += w * dAs[h * 8 + 4];
+      if (col < nd) { sx += w * dAs[h * 8]; sy += w * dAs[h * 8 + 1]; sz += w * dAs[h * 8 + 2]; }
+    }
+    m[col] = s;
+    if (col < nd) { u[col * 3] = sx; u[col * 3 + 1] = sy; u[col * 3 + 2] = sz; }
+  }
+  __syncthreads();
+  const float* z = a.Z + (size_t)b * nd * 3;
+  for (int t = tid; t < nd * 3; t += 256) {
+    const int i = t / 3, k = t - 3 * i;
+    float val = 0.f;
+    if (a.eq == 1) {
+      if (k == 1) {
+        val = m[nd + nd * nd + 1 + i];
+      } else {
+        val = u[i * 3 + k];
+        for (int q = 0; q < nd; ++q) val += (m[nd + i * nd + q] + m[nd + q * nd + i]) * z[q * 3 + k];
+      }
+    } else if (a.eq == 2) {
+      val = u[i * 3 + k];
+      for (int q = 0; q < nd; ++q) val += (m[nd + i * nd + q] + m[nd + q * nd + i]) * z[q * 3 + k];
+    } else {
+      val = u[i * 3 + k] + m[nd + i * 3 + k];
+    }
+    val += 2.f * a.alpha2 * z[t];  // prior term d(alpha |Z|^2) (0 unless RENITestLoss)
+    a.dZ[(size_t)b * nd * 3 + t] = val;
+  }
+}
+
+// dW0[h][col] and db0[h]: sums over the batch of per-image outer products
+__global__ void __launch_bounds__(256) k_tail_dw0(const TailArgs a) {
+  const int F = a.F_in, nd = a.nd, H = a.H, B = a.B;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int h = blockIdx.y;
+  if (col > F) return;
+  if (col == F) {  // bias
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += a.dA[((size_t)b * H + h) * 8 + 4];
+    a.db0[h] = s;
+    return;
+  }
+  float s = 0.f;
+  int kind = 0;  // 0: constant column, 1: inner-product column, 2: r, 3: dy
+  if (col < nd) kind = 1;
+  else if (a.eq == 1 && col == nd + nd * nd) kind = 2;
+  else if (a.eq == 1 && col == F - 1) kind = 3;
+  for (int b = 0; b < B; ++b) {
+    const float* q = a.dA + ((size_t)b * H + h) * 8;
+    if (kind == 0) s += q[4] * a.xconst[(size_t)b * F + col];
+    else if (kind == 1) {
+      const float* z = a.Z + ((size_t)b * nd + col) * 3;
+      if (a.eq == 1) s += q[0] * z[0] + q[2] * z[2];
+      else s += q[0] * z[0] + q[1] * z[1] + q[2] * z[2];
+    } else if (kind == 2) s += q[3];
+    else s += q[1];
+  }
+  a.dW0[(size_t)h * F + col] = s;
+}
+
+__global__ void __launch_bounds__(256) k_adam(float* p, const float* g, float* m, float* v, long long n,
+                                              float lr, float b1, float b2, float eps, float bc1,
+                                              float bc2_sqrt, float gscale) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * gscale;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  // torch.optim.Adam (non-amsgrad): denom = sqrt(v)/sqrt(bias_correction2) + eps; p -= lr/bias_correction1 * m/denom
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] -= (lr / bc1) * (mi / denom);
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA layout probes (reni_selftest_layouts)
+// ------------------------------------------------------------------------------------------
+// probe 0: fp32 32x32x2 : D = A(32x2) B(2x32) with the operand/result maps the kernels assume
+// probe 1: bf16 32x32x16
+__global__ void k_probe(float* outD, int which) {
+  const int lane = threadIdx.x, hi = lane >> 5, j = lane & 31;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (which == 0) {
+    // A[i][k] = 1 + i + 100 k ; B[k][n] = 3 + 2 n + 7 k
+    const float av = 1.f + j + 100.f * hi;
+    const float bv = 3.f + 2.f * j + 7.f * hi;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+  } else {
+    // A[i][k] = ((i + 3k) % 7) - 3 ; B[k][n] = ((2n + k) % 5) - 2 ; k = 8*hi + e  (exact in bf16)
+    bf16x8 av, bv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 8 * hi + e;
+      av[e] = (__bf16)(float)(((j + 3 * k) % 7) - 3);
+      bv[e] = (__bf16)(float)(((2 * j + k) % 5) - 2);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) outD[rowmap(r, hi) * 32 + j] = acc[r];
+}
+
+// explicit instantiations of the fused kernel
+#define RENI_INST(POL, HH)                                                     \
+  template __global__ void k_reni_main<POL, HH, MODE_FWD>(const MainArgs);     \
+  template __global__ void k_reni_main<POL, HH, MODE_STATS>(const MainArgs);   \
+  template __global__ void k_reni_main<POL, HH, MODE_FWD_BWD>(const MainArgs);
+RENI_INST(PolF32, 32)
+RENI_INST(PolF32, 64)
+RENI_INST(PolF32, 128)
+RENI_INST(PolBF16, 32)
+RENI_INST(PolBF16, 64)
+RENI_INST(PolBF16, 128)
+
+}  // namespace reni
+
+#include "reni_capi.inc"

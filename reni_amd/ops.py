@@ -1,0 +1,174 @@
+"""Thin tensor-level wrappers over the C ABI: plans, workspace, and the three compute calls.
+
+PyTorch is plumbing here (device memory, streams); all arithmetic happens in libreni_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.RENILibraryError(
+                "RENI HIP ops need tensors on a GPU device (got a CPU tensor); there is no CPU fallback")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class Plan:
+    """Immutable kernel plan for one decoder architecture (reni_plan_create)."""
+
+    def __init__(self, equivariance: str, ndims: int, hidden_features: int, hidden_layers: int,
+                 out_features: int = 3, last_layer_linear: bool = True, output_activation=None,
+                 first_omega_0: float = 30.0, hidden_omega_0: float = 30.0, dtype: str = "f32"):
+        lib = _lib.load()
+        if equivariance not in _lib.EQ:
+            raise ValueError(f"equivariance {equivariance!r}")
+        if output_activation not in _lib.ACT:
+            raise ValueError(f"output_activation {output_activation!r}")
+        self.desc = _lib.reni_desc(_lib.EQ[equivariance], ndims, hidden_features, hidden_layers, out_features,
+                                   1 if last_layer_linear else 0, _lib.ACT[output_activation],
+                                   float(first_omega_0), float(hidden_omega_0), _lib.DTYPE[dtype])
+        self._h = ctypes.c_void_p()
+        _lib.check(lib.reni_plan_create(ctypes.byref(self.desc), ctypes.byref(self._h)))
+        self.lib = lib
+        self.ndims = ndims
+        self.dtype = dtype
+        self.n_params = int(lib.reni_param_count(self._h))
+        self.in_features = int(lib.reni_in_features(self._h))
+        self._ws = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self.lib.reni_plan_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    # ---- workspace (a torch uint8 tensor, cached per device and size)
+    def workspace(self, B: int, P: int, flags: int, device) -> torch.Tensor:
+        n = int(self.lib.reni_workspace_bytes(self._h, B, P, flags))
+        if n == 0:
+            raise _lib.RENILibraryError("reni_workspace_bytes returned 0 (unsupported configuration)")
+        key = (torch.device(device).index, )
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < n:
+            ws = torch.empty(n + 256, dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    @staticmethod
+    def _aligned_ptr(ws: torch.Tensor) -> Tuple[int, int]:
+        p = ws.data_ptr()
+        ap = (p + 255) & ~255
+        return ap, ws.numel() - (ap - p)
+
+    def launch_info(self, B: int, P: int):
+        info = (ctypes.c_int32 * 4)()
+        _lib.check(self.lib.reni_launch_info(self._h, B, P, info))
+        return {"workgroups": info[0], "threads": info[1], "lds_bytes": info[2], "tiles": info[3]}
+
+    # ---- compute
+    def _grid_args(self, Z, D):
+        B = Z.shape[0]
+        if D.dim() == 2:
+            D = D.unsqueeze(0)
+        if D.shape[0] not in (1, B):
+            raise ValueError(f"directions batch {D.shape[0]} does not match latent batch {B}")
+        P = D.shape[1]
+        dbs = 0 if D.shape[0] == 1 or D.stride(0) == 0 else P * 3
+        if dbs == 0:
+            D = D[:1]
+        return B, P, _f32c(D), dbs
+
+    def forward(self, Z: torch.Tensor, D: torch.Tensor, params: torch.Tensor) -> torch.Tensor:
+        _require_cuda(Z, D, params)
+        Z = _f32c(Z); params = _f32c(params)
+        B, P, Dc, dbs = self._grid_args(Z, D)
+        assert params.numel() == self.n_params and Z.shape[1:] == (self.ndims, 3)
+        out = torch.empty(B, P, 3, dtype=torch.float32, device=Z.device)
+        ws = self.workspace(B, P, 0, Z.device)
+        wp, wn = self._aligned_ptr(ws)
+        stream = torch.cuda.current_stream(Z.device).cuda_stream
+        _lib.check(self.lib.reni_forward(self._h, B, P, Z.data_ptr(), Dc.data_ptr(), dbs, params.data_ptr(),
+                                         out.data_ptr(), wp, wn, stream))
+        return out
+
+    def forward_loss_backward(self, Z, D, params, target, weight, loss_kind="mse", alpha=0.0, beta=0.0,
+                              need_dw=True, need_dz=True, want_out=False):
+        """target / weight: any strided [B,P,3] views (stride 0 broadcasts); returns
+        (loss_terms[4] device tensor, dZ or None, dparams or None, out or None)."""
+        _require_cuda(Z, D, params, target, weight)
+        Z = _f32c(Z); params = _f32c(params)
+        B, P, Dc, dbs = self._grid_args(Z, D)
+        if target.dtype != torch.float32:
+            target = target.float()
+        if weight.dtype != torch.float32:
+            weight = weight.float()
+        target = target.expand(B, P, 3)
+        weight = weight.expand(B, P, 3)
+        ts = (ctypes.c_int64 * 3)(*target.stride())
+        wst = (ctypes.c_int64 * 3)(*weight.stride())
+        flags = (_lib.NEED_DW if need_dw else 0) | (_lib.NEED_DZ if need_dz else 0)
+        dev = Z.device
+        loss_terms = torch.empty(4, dtype=torch.float32, device=dev)
+        dZ = torch.empty_like(Z) if need_dz else None
+        dparams = torch.empty(self.n_params, dtype=torch.float32, device=dev) if need_dw else None
+        out = torch.empty(B, P, 3, dtype=torch.float32, device=dev) if want_out else None
+        ws = self.workspace(B, P, flags, dev)
+        wp, wn = self._aligned_ptr(ws)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        kind = {"mse": _lib.LOSS_MSE, "test": _lib.LOSS_TEST}[loss_kind]
+        _lib.check(self.lib.reni_forward_loss_backward(
+            self._h, B, P, Z.data_ptr(), Dc.data_ptr(), dbs, params.data_ptr(), target.data_ptr(), ts,
+            weight.data_ptr(), wst, kind, float(alpha), float(beta), flags,
+            out.data_ptr() if out is not None else None, loss_terms.data_ptr(),
+            dZ.data_ptr() if dZ is not None else None, dparams.data_ptr() if dparams is not None else None,
+            wp, wn, stream))
+        return loss_terms, dZ, dparams, out
+
+    def backward(self, Z, D, params, dout, need_dw=True, need_dz=True):
+        _require_cuda(Z, D, params, dout)
+        Z = _f32c(Z); params = _f32c(params); dout = _f32c(dout)
+        B, P, Dc, dbs = self._grid_args(Z, D)
+        flags = (_lib.NEED_DW if need_dw else 0) | (_lib.NEED_DZ if need_dz else 0)
+        dev = Z.device
+        dZ = torch.empty_like(Z) if need_dz else None
+        dparams = torch.empty(self.n_params, dtype=torch.float32, device=dev) if need_dw else None
+        ws = self.workspace(B, P, flags, dev)
+        wp, wn = self._aligned_ptr(ws)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(self.lib.reni_backward(
+            self._h, B, P, Z.data_ptr(), Dc.data_ptr(), dbs, params.data_ptr(), dout.data_ptr(), flags,
+            dZ.data_ptr() if dZ is not None else None, dparams.data_ptr() if dparams is not None else None,
+            wp, wn, stream))
+        return dZ, dparams
+
+
+def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,
+              betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
+    """In-place torch.optim.Adam step on flat fp32 buffers (reni_adam_step)."""
+    _require_cuda(p, g, m, v)
+    lib = _lib.load()
+    assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+    stream = torch.cuda.current_stream(p.device).cuda_stream
+    _lib.check(lib.reni_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr),
+                                  float(betas[0]), float(betas[1]), float(eps), int(step), float(grad_scale), stream))
+
+
+def selftest_layouts():
+    lib = _lib.load()
+    out = (ctypes.c_int32 * 2)()
+    _lib.check(lib.reni_selftest_layouts(out, 2))
+    return list(out)
