@@ -1,0 +1,67 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, RCCL over xGMI.
+
+The reference wraps the LightningModule in DDP (run.py:97): every step all-reduces (mean) the
+gradient of every trainable parameter, i.e. the decoder AND the whole latent table.  Here:
+
+* images (their latent rows, Adam moments and target pixels) are owned by rank ``i % world``
+  (what Lightning's DistributedSampler(shuffle=False) over the reference's un-shuffled DataLoader
+  produces);
+* ONE all-reduce(sum) of the flat decoder-gradient buffer per step, then scale 1/world;
+* latent rows need no communication: non-owners would contribute exact zeros, so the owner's
+  gradient x 1/world is the reference's all-reduced value.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1, 0
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def owned_indices(n_items, rank, world):
+    """Indices of the images a rank owns (round-robin, as DistributedSampler(shuffle=False))."""
+    return list(range(rank, n_items, world))
+
+
+def allreduce_mean_(flat: torch.Tensor):
+    """In-place mean all-reduce of one flat buffer (decoder gradients): one collective per step."""
+    w = world_size()
+    if w == 1:
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.mul_(1.0 / w)
+    return flat
+
+
+def broadcast_(flat: torch.Tensor, src=0):
+    """Replicate rank 0's decoder parameters (what DDP does at wrap time, run.py:110)."""
+    if world_size() > 1:
+        dist.broadcast(flat, src=src)
+    return flat
+
+
+def allreduce_mean_scalars(values: torch.Tensor):
+    """Epoch-end metric sync (self.log_dict(..., sync_dist=True), RENI_module.py:156-163)."""
+    w = world_size()
+    if w > 1:
+        dist.all_reduce(values, op=dist.ReduceOp.SUM)
+        values = values / w
+    return values

@@ -1,0 +1,154 @@
+"""CPU-only tests: host-side API parity with the reference's module surface, the C-ABI library
+(loads, exports every declared symbol, validates arguments; no compute without a GPU), grids."""
+import ctypes
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from reni_amd import _lib, utils
+from reni_amd.models import RENIAutoDecoder, RENIVariationalAutoDecoder, get_model
+from tests.util import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "reni_hip.h")).read()
+    declared = set(re.findall(r"\b(reni_[a-z_0-9]+)\s*\(", header))
+    declared -= {"reni_desc", "reni_plan"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_plan_validation_and_counts():
+    from reni_amd.ops import Plan
+    p = Plan("SO2", 36, 128, 5, 3, True, "tanh", 30.0, 30.0, "bf16")
+    assert p.n_params == 258435 and p.in_features == 1370
+    p1 = Plan("SO2", 9, 64, 3, 3, True, None)
+    assert p1.n_params == 19203 and p1.in_features == 101
+    assert Plan("SO3", 49, 128, 5).in_features == 2450
+    assert Plan("None", 9, 64, 3).in_features == 36
+    assert p.lib.reni_workspace_bytes(p._h, 4, 32768, 3) > 0
+    with pytest.raises(_lib.RENILibraryError, match="hidden_features"):
+        Plan("SO2", 9, 100, 3)
+    with pytest.raises(_lib.RENILibraryError, match="out_features"):
+        Plan("SO2", 9, 64, 3, out_features=4)
+    lib = _lib.load()
+    assert lib.reni_plan_create(None, None) < 0 and b"NULL" in lib.reni_last_error()
+
+
+def test_null_and_size_checks_without_gpu():
+    from reni_amd.ops import Plan
+    p = Plan("SO2", 9, 64, 3)
+    lib = p.lib
+    rc = lib.reni_forward(p._h, 1, 128, None, None, 0, None, None, None, 0, None)
+    assert rc == -1 and b"non-NULL" in lib.reni_last_error()
+    rc = lib.reni_forward(p._h, 0, 128, 8, 8, 0, 8, 8, 256, 0, None)
+    assert rc == -1
+    rc = lib.reni_adam_step(None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None)
+    assert rc == -1
+
+
+def test_cpu_tensors_fail_loudly():
+    m = RENIAutoDecoder(2, 9, "SO2", 64, 3, 3, True, "tanh", 30, 30, False)
+    with pytest.raises(_lib.RENILibraryError, match="no CPU fallback"):
+        m(0, torch.zeros(1, 16, 3))
+
+
+@pytest.mark.parametrize("mt,cls", [("AD", RENIAutoDecoder), ("VAD", RENIVariationalAutoDecoder)])
+@pytest.mark.parametrize("eq", ["SO2", "SO3", "None"])
+def test_state_dict_keys_shapes_and_seed_parity(golden, mt, cls, eq):
+    g = golden("g9_api.npz")
+    torch.manual_seed(9)
+    m = cls(3, 9, eq, 64, 3, 3, True, "tanh", 30, 30, False)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g[f"keys_{mt}_{eq}"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g[f"shapes_{mt}_{eq}"])
+    assert m.in_features == int(g[f"infeat_{mt}_{eq}"])
+    if mt == "AD" and eq == "SO2":  # same seed -> same initial weights as the reference, bit for bit
+        for k, v in sd.items():
+            assert np.array_equal(v.numpy(), g["sd." + k]), k
+
+
+def test_flat_parameter_storage_and_reflatten():
+    m = RENIAutoDecoder(2, 9, "SO2", 64, 3, 3, True, "tanh", 30, 30, False)
+    flat = m._flat_params()
+    assert flat.numel() == 19203
+    ps = list(m.net.parameters())
+    assert ps[0].data_ptr() == flat.data_ptr()
+    with torch.no_grad():
+        ps[1].add_(1.0)
+    o = ps[0].numel()
+    assert torch.equal(flat[o:o + 64], ps[1].detach())
+    m2 = m.double().float()  # _apply re-flattens
+    f2 = m2._flat_params()
+    assert list(m2.net.parameters())[2].data_ptr() == f2.data_ptr() + 4 * (ps[0].numel() + ps[1].numel())
+
+
+def test_load_state_dict_remap():
+    torch.manual_seed(1)
+    trained = RENIVariationalAutoDecoder(5, 9, "SO2", 64, 3, 3, True, "tanh", 30, 30, False)
+    ckpt = {"model." + k: v.clone() for k, v in trained.state_dict().items()}
+    frozen = RENIVariationalAutoDecoder(3, 9, "SO2", 64, 3, 3, True, "tanh", 30, 30, True)
+    frozen.load_state_dict(ckpt)  # fixed decoder: only net.* is loaded, latents stay zero (RENI.py:196-201)
+    assert float(frozen.mu.abs().sum()) == 0.0
+    assert all(not p.requires_grad for p in frozen.net.parameters()) and not frozen.log_var.requires_grad
+    for (k1, v1), (k2, v2) in zip(trained.net.state_dict().items(), frozen.net.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    full = RENIVariationalAutoDecoder(5, 9, "SO2", 64, 3, 3, True, "tanh", 30, 30, False)
+    full.load_state_dict(ckpt)
+    assert torch.equal(full.mu, trained.mu) and torch.equal(full.log_var, trained.log_var)
+    assert torch.equal(full._flat_params(), trained._flat_params())
+
+
+def _cfg(**over):
+    r = dict(CONDITIONING="Cond-by-Concat", MODEL_TYPE="AutoDecoder", EQUIVARIANCE="SO2", LATENT_DIMENSION=9,
+             HIDDEN_LAYERS=3, HIDDEN_FEATURES=64, OUT_FEATURES=3, LAST_LAYER_LINEAR=True, OUTPUT_ACTIVATION="tanh",
+             FIRST_OMEGA_0=30.0, HIDDEN_OMEGA_0=30.0, MAPPING_LAYERS=3, MAPPING_FEATURES=64)
+    r.update(over)
+    return types.SimpleNamespace(RENI=types.SimpleNamespace(**r))
+
+
+def test_get_model_factory():
+    m = get_model(_cfg(), 7, "FIT_DECODER")
+    assert isinstance(m, RENIAutoDecoder) and not m.fixed_decoder and m.Z.shape == (7, 9, 3)
+    m = get_model(_cfg(MODEL_TYPE="VariationalAutoDecoder"), 7, "FIT_LATENT")
+    assert isinstance(m, RENIVariationalAutoDecoder) and m.fixed_decoder
+    assert float(m.mu.abs().sum()) == 0.0
+    with pytest.raises(NotImplementedError):
+        get_model(_cfg(CONDITIONING="FiLM"), 7, "FIT_DECODER")
+
+
+def test_vad_sample_latent_matches_reference_stream(golden):
+    g = golden("g8_vad.npz")
+    m = RENIVariationalAutoDecoder(3, 9, "SO2", 64, 3, 3, True, "tanh", 30, 30, False)
+    m.load_state_dict({"model." + k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")})
+    torch.manual_seed(80)
+    Z, mu, lv = m.sample_latent(torch.from_numpy(g["idx"]))
+    np.testing.assert_allclose(Z.detach().numpy(), g["Z"], atol=1e-7)
+
+
+def test_grids_bitwise(golden):
+    g = golden("g1_grids.npz")
+    for W in (32, 64):
+        assert np.array_equal(utils.get_directions(W).numpy(), g[f"dir_{W}"])
+        assert np.array_equal(utils.get_sineweight(W).numpy(), g[f"sw_{W}"])
+    d = utils.get_directions(256)
+    assert np.array_equal(d[0, -64:].numpy(), g["dir_256_tail"])
+
+
+def test_get_mask(tmp_path, golden):
+    from PIL import Image
+    g = golden("g7_latent_opt.npz")
+    src = g["mask_src"]
+    Image.fromarray(np.stack([src] * 3, -1)).save(tmp_path / "m.png")
+    m = utils.get_mask(64, str(tmp_path / "m.png"))
+    assert m.shape == (1, 32 * 64, 3)
+    assert np.array_equal(m.numpy(), g["mask"])
+    assert abs(float(m.mean()) - 0.188) < 0.01  # Mask-3 keeps ~18.8 % of the pixels
