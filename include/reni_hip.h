@@ -132,6 +132,12 @@ int reni_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
  * number of mismatching elements per probe (0 = layout as assumed). */
 int reni_selftest_layouts(int32_t* out_host_mismatch, int32_t n_probes);
 
+/* Optional timing of the fused main kernel (the dominant kernel of the path) with HIP events recorded
+ * on the caller's stream around each launch.  reni_profile_read synchronises the recorded events and
+ * returns their summed duration and count since the last reset.  Used by bench.py for `roofline`. */
+int reni_profile_enable(int32_t on);
+int reni_profile_read(double* total_ms, int64_t* launches, int32_t reset);
+
 /* Launch geometry chosen for (B,P): workgroups, threads, dynamic LDS bytes (diagnostics). */
 int reni_launch_info(const reni_plan* plan, int64_t B, int64_t P, int32_t* info4);
 

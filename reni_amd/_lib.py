@@ -24,7 +24,7 @@ NEED_DW, NEED_DZ = 1, 2
 EXPORTS = (
     "reni_last_error", "reni_plan_create", "reni_plan_destroy", "reni_param_count", "reni_in_features",
     "reni_workspace_bytes", "reni_forward", "reni_forward_loss_backward", "reni_backward",
-    "reni_adam_step", "reni_selftest_layouts", "reni_launch_info",
+    "reni_adam_step", "reni_selftest_layouts", "reni_launch_info", "reni_profile_enable", "reni_profile_read",
 )
 
 
@@ -85,6 +85,10 @@ def load():
     lib.reni_selftest_layouts.restype = c_int32
     lib.reni_launch_info.argtypes = [c_void_p, c_int64, c_int64, POINTER(c_int32)]
     lib.reni_launch_info.restype = c_int32
+    lib.reni_profile_enable.argtypes = [c_int32]
+    lib.reni_profile_enable.restype = c_int32
+    lib.reni_profile_read.argtypes = [POINTER(ctypes.c_double), POINTER(c_int64), c_int32]
+    lib.reni_profile_read.restype = c_int32
     _lib = lib
     return lib
 

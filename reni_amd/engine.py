@@ -1,0 +1,54 @@
+"""Flat-buffer training engine: the fast equivalent of one Lightning training iteration
+(training_step -> backward -> DDP all-reduce -> Adam.step; RENI_module.py:80-146,192, run.py:97)
+for the FIT_DECODER / AutoDecoder case, without per-parameter Python overhead.
+
+One call to ``step`` = fused forward+loss+backward (one kernel launch) -> ONE RCCL all-reduce of the
+flat decoder gradient (mean) -> fused Adam on the flat decoder buffer and on this rank's latent
+rows.  The model object keeps owning the parameters (its nn.Parameters are views of the same flat
+buffer), so ``state_dict()`` stays valid at any time.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import dist as rdist
+from . import ops
+
+
+class TrainEngine:
+    def __init__(self, model, lr: float, loss_kind: str = "mse", alpha: float = 0.0, beta: float = 0.0):
+        self.model = model
+        self.plan = model._plan()
+        self.flat = model._flat_params()
+        assert self.flat.is_cuda, "move the model to the GPU first"
+        self.latent = model.Z if hasattr(model, "Z") else model.mu
+        self.lr = lr
+        self.loss_kind, self.alpha, self.beta = loss_kind, alpha, beta
+        self.train_decoder = not model.fixed_decoder
+        self.m_dec = torch.zeros_like(self.flat)
+        self.v_dec = torch.zeros_like(self.flat)
+        self.m_lat = torch.zeros_like(self.latent.data)
+        self.v_lat = torch.zeros_like(self.latent.data)
+        self.g_lat = torch.zeros_like(self.latent.data)
+        self.t = 0
+        self.world = rdist.world_size()
+
+    def step(self, idx: torch.Tensor, target: torch.Tensor, weight: torch.Tensor, directions: torch.Tensor):
+        """idx: rows of this rank's latent table in the batch; target/weight: strided [B,P,3] views.
+        Returns the device tensor (loss, mse, prior, cosine) of this rank's batch."""
+        Z = self.latent.data[idx]
+        terms, dZ, dparams, _ = self.plan.forward_loss_backward(
+            Z, directions, self.flat, target, weight, loss_kind=self.loss_kind, alpha=self.alpha, beta=self.beta,
+            need_dw=self.train_decoder, need_dz=True)
+        self.t += 1
+        inv_w = 1.0 / self.world
+        if self.train_decoder:
+            if self.world > 1:
+                torch.distributed.all_reduce(dparams, op=torch.distributed.ReduceOp.SUM)
+            ops.adam_step(self.flat, dparams, self.m_dec, self.v_dec, self.t, self.lr, grad_scale=inv_w)
+        # dense Adam over the whole (owned) latent table, as the reference does (rows outside the
+        # batch have zero gradient but still move by momentum -- SURVEY.md Appendix B9)
+        self.g_lat.zero_()
+        self.g_lat.index_add_(0, idx, dZ)
+        ops.adam_step(self.latent.data, self.g_lat, self.m_lat, self.v_lat, self.t, self.lr, grad_scale=inv_w)
+        return terms

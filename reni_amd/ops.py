@@ -172,3 +172,16 @@ def selftest_layouts():
     out = (ctypes.c_int32 * 2)()
     _lib.check(lib.reni_selftest_layouts(out, 2))
     return list(out)
+
+
+def profile_enable(on: bool = True):
+    """Record HIP events around every fused forward+backward kernel launch (reni_profile_enable)."""
+    _lib.check(_lib.load().reni_profile_enable(1 if on else 0))
+
+
+def profile_read(reset: bool = True):
+    """-> (summed kernel milliseconds, number of launches) since the last reset."""
+    tot = ctypes.c_double(0.0)
+    n = ctypes.c_int64(0)
+    _lib.check(_lib.load().reni_profile_read(ctypes.byref(tot), ctypes.byref(n), 1 if reset else 0))
+    return tot.value, n.value
