@@ -138,6 +138,10 @@ int reni_selftest_layouts(int32_t* out_host_mismatch, int32_t n_probes);
 int reni_profile_enable(int32_t on);
 int reni_profile_read(double* total_ms, int64_t* launches, int32_t reset);
 
+/* Diagnostic probe of the LDS transpose-read instruction (ds_read_b64_tr_b16): LDS holds u16 element i = i;
+ * lane l reads at byte address 8*l (mode 0) or lane_addr_host[l] (mode 1); out_host[4*l + e] = element e. */
+int reni_probe_tr(const int32_t* lane_addr_host, int32_t mode, uint16_t* out_host);
+
 /* Launch geometry chosen for (B,P): workgroups, threads, dynamic LDS bytes (diagnostics). */
 int reni_launch_info(const reni_plan* plan, int64_t B, int64_t P, int32_t* info4);
 

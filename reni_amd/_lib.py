@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libreni_hip.so")
+LIB_PATH = os.environ.get("RENI_HIP_LIB") or os.path.join(_HERE, "lib", "libreni_hip.so")  # env override: kernel experiments
 
 RENI_OK = 0
 EQ = {"None": 0, None: 0, "SO2": 1, "SO3": 2}
@@ -24,7 +24,7 @@ NEED_DW, NEED_DZ = 1, 2
 EXPORTS = (
     "reni_last_error", "reni_plan_create", "reni_plan_destroy", "reni_param_count", "reni_in_features",
     "reni_workspace_bytes", "reni_forward", "reni_forward_loss_backward", "reni_backward",
-    "reni_adam_step", "reni_selftest_layouts", "reni_launch_info", "reni_profile_enable", "reni_profile_read",
+    "reni_adam_step", "reni_selftest_layouts", "reni_launch_info", "reni_profile_enable", "reni_profile_read", "reni_probe_tr",
 )
 
 

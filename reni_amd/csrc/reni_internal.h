@@ -11,6 +11,7 @@ struct MainArgs {
   // geometry
   int B, P, tiles_per_image, n_tiles;
   int L, last_linear, act, loss_kind, need_dw;
+  int dbg;  // ablation mask for profiling experiments (RENI_DEBUG_MASK); 0 in production
   float w_first, w_hidden, beta;
   // inputs
   const float* Z;
@@ -36,6 +37,8 @@ struct MainArgs {
   unsigned p_off_b[MAX_LAYERS + 2];
   float* dA_part;    // [n_tiles][H][16]
   float* loss_part;  // [n_tiles][4][16]
+  char* g1;          // [n_tiles][H/16][256][16 B] bf16 g_1 stream (persistent training path)
+  long long* trace;  // optional (tag, s_memtime) pairs from workgroup 0 (RENI_TRACE builds)
 };
 
 struct PrepArgs {

@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "reni_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -308,30 +310,41 @@ DEV float frag_sum(typename Pol::Frag a) {
 
 enum { DW_HIDDEN = 0, DW_HEAD = 1, DW_L0 = 2 };
 
-// dM[row-feature][col-feature] (+)= sum over the tile's 128 samples rows[.][s] * cols[.][s].
-//   DW_HIDDEN: rows = g_a (layer outputs), cols = h_{l-1}; flushed to dW_l [out][in] and db_l
-//   DW_HEAD  : rows = h_L, cols = g_y (3 real);            flushed to dW_out[c][feature], db_out
-//   DW_L0    : rows = g_a0, cols = (x_hi[5], x_lo[4]);     stored to the per-tile dA partial
-template <class Pol, int H, int NBR, int NBC, int KIND>
-DEV void dw_phase(char* TA, char* TB, const float (&rows)[NBR][16], const float (&cols)[NBC][16],
-                  float* dst_w, float* dst_b, int ldw, bool first, int wave, int lane) {
+// MFMA with the accumulator PINNED to the AGPR half ("a") or the VGPR half ("v") of the register
+// file.  hipcc puts every MFMA accumulator of a kernel into AGPRs (256 = sixteen 32x32 tiles); the
+// persistent training kernel needs twenty-odd live tiles, so it pins them by hand.  Operands come
+// straight from ds_read (the compiler's s_waitcnt covers them) and the accumulator is only ever
+// touched by these statements, so no MFMA hazard crosses the asm boundary (cdna guide, 5.7).
+// hipcc neither pads hazards inside an asm statement nor knows that the statement is an MFMA, so the
+// wait states are part of the string: `s_nop 4` in front covers a compiler-generated VALU / v_accvgpr_write
+// of an operand just before (e.g. a reload of a spilled tile); LAST = the final MFMA of a chain on this
+// tile is followed by 20 wait states so that a compiler read of the result (v_accvgpr_read for a spill,
+// the final flush) never overtakes the 8-pass XDL write-back.
+template <bool LAST>
+DEV void mfma_bf16_pin_a(f32x16& acc, bf16x8 a, bf16x8 b) {
+  if constexpr (LAST)
+    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+a"(acc) : "v"(a), "v"(b));
+  else
+    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+template <bool LAST>
+DEV void mfma_bf16_pin_v(f32x16& acc, bf16x8 a, bf16x8 b) {
+  if constexpr (LAST)
+    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(acc) : "v"(a), "v"(b));
+  else
+    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+// K = samples GEMM from the transposed LDS images: acc[m] += rows-block x cols-block over one round
+// PIN: 0 = compiler-allocated accumulator, 1 = pinned to AGPRs, 2 = pinned to VGPRs (bf16 only)
+template <class Pol, int H, int NBR, int NBC, int KIND, int MYB, int PIN = 0>
+DEV void dw_gemm(const char* TA, const char* TB, f32x16 (&acc)[MYB], float& dbacc, int wave, int lane) {
   using G = Geo<Pol, H>;
+  using Frag = typename Pol::Frag;
   constexpr int NBLK = NBR * NBC;
-  constexpr int MYB = (NBLK + 3) / 4;
-  constexpr int NROUND = 4 / Pol::ROUND_WAVES;
   constexpr int NKS_T = G::ROUND_SAMPLES / Pol::TS;
   const int hi = lane >> 5, j = lane & 31;
-  f32x16 acc[MYB];
-  acc_zero<MYB>(acc);
-  float dbacc = 0.f;
-#pragma unroll 1
-  for (int round = 0; round < NROUND; ++round) {
-    __syncthreads();
-    if (wave / Pol::ROUND_WAVES == round) {
-      t_write<Pol, H, NBR>(TA, rows, wave % Pol::ROUND_WAVES, hi, j);
-      t_write<Pol, H, NBC>(TB, cols, wave % Pol::ROUND_WAVES, hi, j);
-    }
-    __syncthreads();
+  if constexpr (PIN == 0) {
 #pragma unroll
     for (int ks = 0; ks < NKS_T; ++ks) {
 #pragma unroll
@@ -339,16 +352,47 @@ DEV void dw_phase(char* TA, char* TB, const float (&rows)[NBR][16], const float 
         const int blk = wave + 4 * m;
         if (blk < NBLK) {
           const int rbo = blk % NBR, cb = blk / NBR;
-          typename Pol::Frag fa = t_read<Pol, H, NBR>(TA, rbo, ks, j, hi);
-          typename Pol::Frag fb = t_read<Pol, H, NBC>(TB, cb, ks, j, hi);
+          Frag fa = t_read<Pol, H, NBR>(TA, rbo, ks, j, hi);
+          Frag fb = t_read<Pol, H, NBC>(TB, cb, ks, j, hi);
           acc[m] = Pol::mfma(fa, fb, acc[m]);
           if (KIND == DW_HIDDEN && m == 0 && cb == 0) dbacc += frag_sum<Pol>(fa);
-          if (KIND == DW_HEAD && m == 0 && blk == 0) dbacc += frag_sum<Pol>(fb);
+          if (KIND == DW_HIDDEN ? false : (KIND == DW_HEAD && m == 0 && blk == 0)) dbacc += frag_sum<Pol>(fb);
         }
       }
     }
+  } else {
+    // pinned accumulators (persistent training kernel: NBR == 4, every wave owns row block `wave`
+    // and all MYB column blocks).  Fragments are fetched one k-step ahead and the schedule is fenced
+    // per k-step so that no more than two k-steps of fragments are ever live.
+    static_assert(NBLK == 4 * MYB, "pinned form: every wave owns exactly MYB blocks");
+#pragma unroll
+    for (int ks = 0; ks < NKS_T; ++ks) {
+#pragma unroll
+      for (int m = 0; m < MYB; ++m) {
+        const int blk = wave + 4 * m;
+        Frag fa = t_read<Pol, H, NBR>(TA, blk % NBR, ks, j, hi);
+        Frag fb = t_read<Pol, H, NBC>(TB, blk / NBR, ks, j, hi);
+        constexpr bool kLast = false;
+        if (ks == NKS_T - 1 && m == MYB - 1) {
+          if constexpr (PIN == 1) mfma_bf16_pin_a<true>(acc[m], fa, fb);
+          else mfma_bf16_pin_v<true>(acc[m], fa, fb);
+        } else {
+          if constexpr (PIN == 1) mfma_bf16_pin_a<kLast>(acc[m], fa, fb);
+          else mfma_bf16_pin_v<kLast>(acc[m], fa, fb);
+        }
+        if (KIND == DW_HIDDEN && m == 0 && (wave / NBR) == 0) dbacc += frag_sum<Pol>(fa);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
-  // ---- flush
+}
+
+// write the accumulated block(s) to the flat-layout destination (plain store when `first`, else +=)
+template <class Pol, int H, int NBR, int NBC, int KIND, int MYB>
+DEV void dw_flush(const f32x16 (&acc)[MYB], float dbacc, float* dst_w, float* dst_b, int ldw, bool first,
+                  int wave, int lane, int amode = 0) {
+  constexpr int NBLK = NBR * NBC;
+  const int hi = lane >> 5, j = lane & 31;
 #pragma unroll
   for (int m = 0; m < MYB; ++m) {
     const int blk = wave + 4 * m;
@@ -359,7 +403,18 @@ DEV void dw_phase(char* TA, char* TB, const float (&rows)[NBR][16], const float 
         const int row = 32 * rbo + rowmap(r, hi);
         if constexpr (KIND == DW_HIDDEN) {
           float* p = dst_w + (size_t)row * ldw + 32 * cb + j;
-          *p = first ? acc[m][r] : (*p + acc[m][r]);
+          if (amode == 1) {
+            __hip_atomic_fetch_add(p, acc[m][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else if (amode == 2) {
+            const float t = acc[m][r] * 4096.f;  // 2^(44-32)
+            const float h = floorf(t);
+            const unsigned lo = (unsigned)((t - h) * 4294967296.f);
+            const unsigned long long q = ((unsigned long long)(unsigned)(int)h << 32) | lo;
+            __hip_atomic_fetch_add((unsigned long long*)dst_w + ((size_t)row * ldw + 32 * cb + j), q, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            *p = first ? acc[m][r] : (*p + acc[m][r]);
+          }
         } else if constexpr (KIND == DW_HEAD) {
           if (j < 3) {
             float* p = dst_w + (size_t)j * ldw + row;
@@ -386,15 +441,83 @@ DEV void dw_phase(char* TA, char* TB, const float (&rows)[NBR][16], const float 
   }
 }
 
+// transposition round(s) + K = samples GEMM into caller-owned accumulators (no flush)
+template <class Pol, int H, int NBR, int NBC, int KIND, int MYB, int PIN>
+DEV void dw_accum(char* TA, char* TB, const float (&rows)[NBR][16], const float (&cols)[NBC][16],
+                  f32x16 (&acc)[MYB], float& dbacc, int wave, int lane) {
+  constexpr int NROUND = 4 / Pol::ROUND_WAVES;
+  const int hi = lane >> 5, j = lane & 31;
+#pragma unroll 1
+  for (int round = 0; round < NROUND; ++round) {
+    __syncthreads();
+    if (wave / Pol::ROUND_WAVES == round) {
+      t_write<Pol, H, NBR>(TA, rows, wave % Pol::ROUND_WAVES, hi, j);
+      t_write<Pol, H, NBC>(TB, cols, wave % Pol::ROUND_WAVES, hi, j);
+    }
+    __syncthreads();
+    dw_gemm<Pol, H, NBR, NBC, KIND, MYB, PIN>(TA, TB, acc, dbacc, wave, lane);
+  }
+}
+
+// dM[row-feature][col-feature] (+)= sum over the tile's 128 samples rows[.][s] * cols[.][s].
+//   DW_HIDDEN: rows = g_a (layer outputs), cols = h_{l-1}; flushed to dW_l [out][in] and db_l
+//   DW_HEAD  : rows = h_L, cols = g_y (3 real);            flushed to dW_out[c][feature], db_out
+//   DW_L0    : rows = g_a0, cols = (x_hi[5], x_lo[4]);     stored to the per-tile dA partial
+// dbg: ablation mask for profiling experiments (1 = no flush, 2 = no GEMM, 4 = no LDS transposition)
+template <class Pol, int H, int NBR, int NBC, int KIND>
+DEV void dw_phase(char* TA, char* TB, const float (&rows)[NBR][16], const float (&cols)[NBC][16],
+                  float* dst_w, float* dst_b, int ldw, bool first, int wave, int lane, int dbg = 0) {
+  constexpr int MYB = (NBR * NBC + 3) / 4;
+  constexpr int NROUND = 4 / Pol::ROUND_WAVES;
+  const int hi = lane >> 5, j = lane & 31;
+  f32x16 acc[MYB];
+  acc_zero<MYB>(acc);
+  float dbacc = 0.f;
+#pragma unroll 1
+  for (int round = 0; round < NROUND; ++round) {
+    __syncthreads();
+    if (wave / Pol::ROUND_WAVES == round && !(dbg & 4)) {
+      t_write<Pol, H, NBR>(TA, rows, wave % Pol::ROUND_WAVES, hi, j);
+      t_write<Pol, H, NBC>(TB, cols, wave % Pol::ROUND_WAVES, hi, j);
+    }
+    __syncthreads();
+    if (dbg & 2) continue;
+    dw_gemm<Pol, H, NBR, NBC, KIND, MYB>(TA, TB, acc, dbacc, wave, lane);
+  }
+  if (dbg & 1) {
+    float keep = dbacc;
+#pragma unroll
+    for (int m = 0; m < MYB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) keep += acc[m][r];
+    if (keep == 123.456f) dst_w[0] = keep;
+    return;
+  }
+  dw_flush<Pol, H, NBR, NBC, KIND, MYB>(acc, dbacc, dst_w, dst_b, ldw, first, wave, lane, (dbg >> 8) & 3);
+}
+
 // ------------------------------------------------------------------------------------------
 // the fused kernel
 // ------------------------------------------------------------------------------------------
 enum { MODE_FWD = 0, MODE_STATS = 1, MODE_FWD_BWD = 2 };
 
-template <class Pol, int H, int MODE>
-__global__ void __launch_bounds__(256, Pol::WPS) k_reni_main(const MainArgs a) {
+// PERSIST (bf16 training only, L <= PMAX hidden layers): the dW_l accumulators of every hidden layer
+// live in registers for the workgroup's whole tile loop -- 4 layers pinned to the AGPR half of the
+// register file, the fifth to VGPRs -- and are written once per launch.  One workgroup per CU
+// (one wave per SIMD, up to 512 registers).  The per-tile "+=" flush of the generic form was 65 % of
+// its run time (profiles/r01_b_ablation.md).
+template <class Pol, int H, int MODE, bool PERSIST = false>
+__global__ void __launch_bounds__(256, (PERSIST ? 1 : Pol::WPS)) k_reni_main(const MainArgs a) {
   using G = Geo<Pol, H>;
   constexpr int NRB = G::NRB;
+  constexpr int MYB_H = (NRB * NRB + 3) / 4;
+  constexpr int PMAX = 5;
+  f32x16 pacc[PERSIST ? PMAX : 1][MYB_H];
+  float pdb[PERSIST ? PMAX : 1];
+  if constexpr (PERSIST) {
+#pragma unroll
+    for (int l = 0; l < PMAX; ++l) { acc_zero<MYB_H>(pacc[l]); pdb[l] = 0.f; }
+  }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const WB = smem;
   char* const TA = smem;  // aliases WB: the weight image is dead while a dW phase runs
@@ -404,7 +527,12 @@ __global__ void __launch_bounds__(256, Pol::WPS) k_reni_main(const MainArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, hi = lane >> 5, j = lane & 31;
   char* const stash = a.stash + (size_t)blockIdx.x * a.stash_per_wg;
-  float* const dwp = a.dwp + (size_t)blockIdx.x * a.dwp_per_wg;
+  float* dwp_sel = a.dwp + (size_t)blockIdx.x * a.dwp_per_wg;
+  if (a.dbg & 0x300) {  // experiment: atomics into per-XCD (or one) shared partial buffers
+    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
+    dwp_sel = a.dwp + (size_t)((a.dbg & 0x400) ? 0 : xcc) * 2 * a.dwp_per_wg;
+  }
+  float* const dwp = dwp_sel;
   const int L = a.L;
   bool first = true;
 
@@ -474,7 +602,7 @@ __global__ void __launch_bounds__(256, Pol::WPS) k_reni_main(const MainArgs a) {
 #pragma unroll 1
     for (int l = 1; l <= L; ++l) {
       __syncthreads();
-      stage_to_lds(WB, a.wimg + a.fwd_off[l], G::IMG_HID + G::BIAS_HID, tid);
+      if (!(a.dbg & 32)) stage_to_lds(WB, a.wimg + a.fwd_off[l], G::IMG_HID + G::BIAS_HID, tid);
       __syncthreads();
       f32x16 acc[NRB];
       acc_init_bias<Pol, NRB>(acc, (const float*)(WB + G::IMG_HID), hi);
@@ -565,8 +693,8 @@ __global__ void __launch_bounds__(256, Pol::WPS) k_reni_main(const MainArgs a) {
       float gh[1][16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) gh[0][r] = (r < 3) ? gy[r] : 0.f;
-      if (a.need_dw)
-        dw_phase<Pol, H, NRB, 1, DW_HEAD>(TA, TB, v, gh, dwp + a.p_off_w[L + 1], dwp + a.p_off_b[L + 1], H, first, wave, lane);
+      if (a.need_dw && !(a.dbg & 128))
+        dw_phase<Pol, H, NRB, 1, DW_HEAD>(TA, TB, v, gh, dwp + a.p_off_w[L + 1], dwp + a.p_off_b[L + 1], H, first, wave, lane, a.dbg);
       __syncthreads();
       stage_to_lds(WB, a.wimg + a.bwd_off[L + 1], G::IMG_HB, tid);
       __syncthreads();
@@ -576,14 +704,25 @@ __global__ void __launch_bounds__(256, Pol::WPS) k_reni_main(const MainArgs a) {
 #pragma unroll 1
     for (int l = L; l >= 1; --l) {
       act_replay<Pol, NRB, 0>(g, acc, a.w_hidden, a.w_hidden, stash + (size_t)l * G::STASH_LAYER_BYTES, tid);
-      if (a.need_dw) {
+      if (a.need_dw && !(a.dbg & 128)) {
         float hp[NRB][16];
         act_replay<Pol, NRB, 1>(hp, nullptr, (l - 1 == 0) ? a.w_first : a.w_hidden, 0.f,
                                 stash + (size_t)(l - 1) * G::STASH_LAYER_BYTES, tid);
-        dw_phase<Pol, H, NRB, NRB, DW_HIDDEN>(TA, TB, g, hp, dwp + a.p_off_w[l], dwp + a.p_off_b[l], H, first, wave, lane);
+        if constexpr (PERSIST) {
+          // one static register set per layer; layers 2..5 in AGPRs, layer 1 in VGPRs
+          switch (l) {
+            case 5: dw_accum<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, g, hp, pacc[4], pdb[4], wave, lane); break;
+            case 4: dw_accum<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, g, hp, pacc[3], pdb[3], wave, lane); break;
+            case 3: dw_accum<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, g, hp, pacc[2], pdb[2], wave, lane); break;
+            case 2: dw_accum<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, g, hp, pacc[1], pdb[1], wave, lane); break;
+            default: dw_accum<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 2>(TA, TB, g, hp, pacc[0], pdb[0], wave, lane); break;
+          }
+        } else {
+          dw_phase<Pol, H, NRB, NRB, DW_HIDDEN>(TA, TB, g, hp, dwp + a.p_off_w[l], dwp + a.p_off_b[l], H, first, wave, lane, a.dbg);
+        }
       }
       __syncthreads();
-      stage_to_lds(WB, a.wimg + a.bwd_off[l], G::IMG_HID, tid);
+      if (!(a.dbg & 32)) stage_to_lds(WB, a.wimg + a.bwd_off[l], G::IMG_HID, tid);
       __syncthreads();
       acc_zero<NRB>(acc);
       gemm_lds<Pol, NRB, NRB, G::NKS>(WB, g, acc, lane);
@@ -606,11 +745,507 @@ __global__ void __launch_bounds__(256, Pol::WPS) k_reni_main(const MainArgs a) {
       } else {
         xc[0][0] = 1.f;
       }
-      dw_phase<Pol, H, NRB, 1, DW_L0>(TA, TB, g, xc, a.dA_part + (size_t)tile * H * 16, nullptr, 16, true, wave, lane);
+      dw_phase<Pol, H, NRB, 1, DW_L0>(TA, TB, g, xc, a.dA_part + (size_t)tile * H * 16, nullptr, 16, true, wave, lane, a.dbg & ~3);
     }
     first = false;
   }
+  if constexpr (PERSIST) {
+    // the only write of the hidden-layer weight-gradient partials: once per workgroup per launch
+#pragma unroll
+    for (int l = 1; l <= PMAX; ++l)
+      if (l <= L)
+        dw_flush<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H>(pacc[l - 1], pdb[l - 1], dwp + a.p_off_w[l], dwp + a.p_off_b[l], H, true, wave, lane);
+  }
 }
+
+// ==========================================================================================
+// bf16 TRAINING kernel with register-persistent weight-gradient accumulators
+// ==========================================================================================
+// Same arithmetic as k_reni_main<PolBF16, H, MODE_FWD_BWD>, different schedule:
+//   * exactly LP hidden layers (compile time): the dW_l accumulators (LP x H x H fp32 = 320 KB for
+//     5 x 128^2, 62 % of a CU's register file) live in AGPRs/VGPRs across the workgroup's whole
+//     tile loop and are written ONCE per launch -- the generic kernel's per-tile "+=" flush of the
+//     partials was 65 % of its run time (profiles/r01_b_ablation.md);
+//   * one workgroup (4 waves, one per SIMD, up to 512 registers each) per CU;
+//   * activations travel between layers as packed bf16 MFMA operands (no fp32 copies);
+//   * weight images are double-buffered in LDS and fetched one step ahead by LDS-DMA
+//     (global_load_lds), so a step has one barrier (forward) or two (backward), no staging stall.
+template <int N, class F>
+DEV void static_for_down(F&& f) {
+  if constexpr (N >= 1) {
+    f(std::integral_constant<int, N>{});
+    static_for_down<N - 1>(f);
+  }
+}
+
+template <int H>
+struct GeoP {
+  using G = Geo<PolBF16, H>;
+  static constexpr int WBSZ = (G::IMG_HID + G::BIAS_HID + 1023) & ~1023;  // DMA moves 1 KB pieces
+  static constexpr int TSZ = G::T_BYTES_AL;
+  static constexpr int LDS_BYTES = 2 * WBSZ + 2 * TSZ;
+};
+
+// async global -> LDS copy of `bytes` (rounded up to 1 KB; the image regions are padded) split over 4 waves
+template <int BYTES>
+DEV void dma_image(char* lds_dst, const char* gsrc, int wave, int lane16) {
+  constexpr int NP = (BYTES + 1023) / 1024;
+  const char* src = gsrc + lane16;  // lane16 is opaque per tile iteration: keeps this address math out of LICM
+#pragma unroll
+  for (int pi = 0; pi < (NP + 3) / 4; ++pi) {
+    const int piece = pi * 4 + wave;
+    if (piece < NP)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                       (__attribute__((address_space(3))) void*)(lds_dst + piece * 1024), 16, 0, 0);
+  }
+}
+
+// acc[rbo] (+)= W-image[rbo] . bop   (row-block-outer order so the caller's per-row-block epilogue
+// overlaps the next row block's MFMAs)
+template <int NKS>
+DEV f32x16 gemm_rb(const char* wb, int rbo, const bf16x8 (&bop)[NKS], f32x16 acc, int lane) {
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    bf16x8 a = *(const bf16x8*)(wb + ((rbo * NKS + ks) * 64 + lane) * 16);
+    acc = PolBF16::mfma(a, bop[ks], acc);
+  }
+  return acc;
+}
+
+template <int H, int NB>
+DEV void t_write_b(char* T, const bf16x8 (&xb)[2 * NB], int wave, int hi, int j) {
+  using G = Geo<PolBF16, H>;
+#pragma unroll
+  for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      *(__bf16*)(T + (32 * rb + rowmap(r, hi)) * G::T_ROWB + (wave * 32 + j) * 2) = xb[2 * rb + (r >> 3)][r & 7];
+}
+
+// phase (revolutions, u16) pair in one dword -> two floats in [1,2): sin/cos of 2*pi*x are periodic in 1
+DEV float phase_lo(unsigned w) { return __uint_as_float(((w & 0xffffu) << 7) | 0x3f800000u); }
+DEV float phase_hi(unsigned w) { return __uint_as_float(((w >> 9) & 0x007fff80u) | 0x3f800000u); }
+
+// ==========================================================================================
+// bf16 TRAINING kernel with register-persistent weight-gradient accumulators (H = 128, L <= 5)
+// ==========================================================================================
+// Same arithmetic as k_reni_main<PolBF16, 128, MODE_FWD_BWD>, different schedule:
+//   * the dW_l accumulators of all hidden layers (5 x 128 x 128 fp32 = 320 KB per workgroup, 62 % of a
+//     CU's register file) stay in registers across the workgroup's whole tile loop and are written
+//     ONCE per launch.  hipcc allocates every MFMA accumulator of a kernel in AGPRs (256 = sixteen
+//     32x32 tiles), so the tiles are pinned by hand: layers 2..5 in AGPRs, layer 1 in VGPRs
+//     (mfma_bf16_pin_a / _v).  The generic kernel's per-tile "+=" flush of those partials was 65 % of
+//     its run time (profiles/r01_b_ablation.md);
+//   * one workgroup (4 waves, one per SIMD, up to 512 registers each) per CU;
+//   * activations / gradients travel between layers as packed bf16 MFMA operands;
+//   * weight images are double-buffered in LDS and fetched one step ahead by LDS-DMA
+//     (global_load_lds): one barrier per forward layer, two per backward layer, no staging stall.
+template <int H>
+__global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
+  using Pol = PolBF16;
+  using G = Geo<Pol, H>;
+  using GP = GeoP<H>;
+  constexpr int NRB = G::NRB, NKS = G::NKS;
+  constexpr int MYB_H = (NRB * NRB + 3) / 4;
+  constexpr int PMAX = 5;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const TA = smem + 2 * GP::WBSZ;
+  char* const TB = TA + GP::TSZ;
+
+#ifdef RENI_TRACE
+  int trace_n = 0;
+#define TRACE(tag) do { __builtin_amdgcn_sched_barrier(0); if (a.trace && blockIdx.x == 0 && threadIdx.x == 0 && trace_n < 250) { a.trace[2 * trace_n] = (long long)(tag); a.trace[2 * trace_n + 1] = (long long)__builtin_amdgcn_s_memtime(); ++trace_n; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TRACE(tag) do {} while (0)
+#endif
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, hi = lane >> 5, j = lane & 31;
+  char* const stash = a.stash + (size_t)blockIdx.x * a.stash_per_wg;
+  float* const dwp = a.dwp + (size_t)blockIdx.x * a.dwp_per_wg;
+  const int L = a.L;
+  const int nstep = 2 * L + 2;  // weight images consumed per tile
+
+  f32x16 pacc[PMAX][MYB_H];
+  float pdb[PMAX];
+#pragma unroll
+  for (int l = 0; l < PMAX; ++l) { acc_zero<MYB_H>(pacc[l]); pdb[l] = 0.f; }
+  bool first = true;
+
+  int lane16 = lane * 16, tid16 = tid * 16;  // re-made opaque at the top of every tile iteration
+  // image of step k of a tile: k < L hidden fwd (layer k+1), k == L head fwd, k == L+1 head bwd,
+  // then hidden bwd for layer 2L+2-k.  Buffer = k & 1.
+  auto issue_dma = [&](int k) {
+    char* dst = smem + (k & 1) * GP::WBSZ;
+    if (k < L) dma_image<G::IMG_HID + G::BIAS_HID>(dst, a.wimg + a.fwd_off[k + 1], wave, lane16);
+    else if (k == L) dma_image<G::IMG_HF + G::BIAS_HEAD>(dst, a.wimg + a.fwd_off[L + 1], wave, lane16);
+    else if (k == L + 1) dma_image<G::IMG_HB>(dst, a.wimg + a.bwd_off[L + 1], wave, lane16);
+    else dma_image<G::IMG_HID>(dst, a.wimg + a.bwd_off[2 * L + 2 - k], wave, lane16);
+  };
+  issue_dma(0);
+  const float sc_first = a.w_first * 0.15915494309189535f, sc_hidden = a.w_hidden * 0.15915494309189535f;
+
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    asm volatile("" : "+v"(lane16), "+v"(tid16));
+    TRACE(1);
+    const int b = tile / a.tiles_per_image;
+    const int p = (tile - b * a.tiles_per_image) * 128 + wave * 32 + j;
+    const bool valid = p < a.P;
+    float x[5];
+    {
+      const float* dp = a.D + (size_t)b * a.d_bstride + (size_t)(valid ? p : 0) * 3;
+      x[0] = dp[0]; x[1] = dp[1]; x[2] = dp[2];
+      x[3] = sqrtf(x[0] * x[0] + x[2] * x[2]);
+      x[4] = 1.f;
+    }
+    __bf16 xh[5], xl[4];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) xh[k] = (__bf16)x[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xl[k] = (__bf16)(x[k] - (float)xh[k]);
+
+    bf16x8 hb[NKS];  // current activations as MFMA B operands
+
+    // activation of one finished row block: stash the phase, keep bf16 sin
+    auto activate = [&](const f32x16& acc, int rb, float sc, bf16x8 (&dst)[NKS], char* sl) {
+      unsigned q[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float th = __builtin_amdgcn_fractf(acc[r] * sc);
+        q[r] = ((unsigned)(th * 65536.f + 0.5f)) & 0xffffu;
+        dst[2 * rb + (r >> 3)][r & 7] = (__bf16)__builtin_amdgcn_sinf(th);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        u32x4 w;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) w[d] = q[8 * c + 2 * d] | (q[8 * c + 2 * d + 1] << 16);
+        *(u32x4*)(sl + (2 * rb + c) * 4096 + tid16) = w;
+      }
+    };
+
+    // ---- layer 0 (per-image affine map, split-bf16 operands: see k_reni_main)
+    {
+      const float* Ab = a.Apre + (size_t)b * H * 8;
+      bf16x8 bop;
+      if (hi == 0) { bop[0] = xh[0]; bop[1] = xh[1]; bop[2] = xh[2]; bop[3] = xh[3]; bop[4] = xh[4]; bop[5] = xh[0]; bop[6] = xh[1]; bop[7] = xh[2]; }
+      else { bop[0] = xh[3]; bop[1] = xh[4]; bop[2] = xl[0]; bop[3] = xl[1]; bop[4] = xl[2]; bop[5] = xl[3]; bop[6] = (__bf16)0.f; bop[7] = (__bf16)0.f; }
+#pragma unroll
+      for (int rbo = 0; rbo < NRB; ++rbo) {
+        const f32x4 lo4 = *(const f32x4*)(Ab + (32 * rbo + j) * 8);
+        const float a4 = Ab[(32 * rbo + j) * 8 + 4];
+        const float A5[5] = {lo4[0], lo4[1], lo4[2], lo4[3], a4};
+        __bf16 Ah[5], Al[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { Ah[k] = (__bf16)A5[k]; Al[k] = (__bf16)(A5[k] - (float)Ah[k]); }
+        bf16x8 aop;
+        if (hi == 0) { aop[0] = Ah[0]; aop[1] = Ah[1]; aop[2] = Ah[2]; aop[3] = Ah[3]; aop[4] = Ah[4]; aop[5] = Al[0]; aop[6] = Al[1]; aop[7] = Al[2]; }
+        else { aop[0] = Al[3]; aop[1] = Al[4]; aop[2] = Ah[0]; aop[3] = Ah[1]; aop[4] = Ah[2]; aop[5] = Ah[3]; aop[6] = (__bf16)0.f; aop[7] = (__bf16)0.f; }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = PolBF16::mfma(aop, bop, acc);
+        activate(acc, rbo, sc_first, hb, stash);
+      }
+    }
+
+    TRACE(2);
+    // ---- hidden layers (step k = l - 1)
+#pragma unroll 1
+    for (int l = 1; l <= L; ++l) {
+      __syncthreads();  // image of this step landed (vmcnt(0) before the barrier); the other buffer is free
+      TRACE(10 + l);
+      issue_dma(l);
+      const char* wb = smem + ((l - 1) & 1) * GP::WBSZ;
+      const float* bias = (const float*)(wb + G::IMG_HID);
+      char* sl = stash + (size_t)l * G::STASH_LAYER_BYTES;
+      bf16x8 hn[NKS];
+#pragma unroll
+      for (int rbo = 0; rbo < NRB; ++rbo) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias[32 * rbo + rowmap(r, hi)];
+        acc = gemm_rb<NKS>(wb, rbo, hb, acc, lane);
+        activate(acc, rbo, sc_hidden, hn, sl);
+      }
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) hb[ks] = hn[ks];
+    }
+
+    TRACE(3);
+    // ---- head (step L)
+    float ylin[3], outv[3];
+    {
+      __syncthreads();
+      TRACE(4);
+      issue_dma(L + 1);
+      const char* wb = smem + (L & 1) * GP::WBSZ;
+      const float* bias = (const float*)(wb + G::IMG_HF);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = bias[rowmap(r, hi)];
+      acc = gemm_rb<NKS>(wb, 0, hb, acc, lane);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        ylin[c] = acc[c];
+        const float yv = a.last_linear ? ylin[c] : sin_f32(a.w_hidden * ylin[c]);
+        outv[c] = (a.act == 1) ? tanhf(yv) : (a.act == 2) ? expf(yv) : yv;
+      }
+    }
+    const bool owner = valid && (hi == 0);
+    if (a.out != nullptr && owner) {
+      float* op = a.out + ((size_t)b * a.P + p) * 3;
+      op[0] = outv[0]; op[1] = outv[1]; op[2] = outv[2];
+    }
+
+    TRACE(5);
+    // ---- loss and d loss / d out
+    float gy[3] = {0.f, 0.f, 0.f};
+    {
+      float e = 0.f;
+      if (a.loss_kind == 2) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gy[c] = owner ? a.dout[((size_t)b * a.P + p) * 3 + c] : 0.f;
+      } else {
+        const float inv3p = 1.0f / (3.0f * (float)a.P);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (owner) {
+            const float t = a.target[(size_t)b * a.ts0 + (size_t)p * a.ts1 + (size_t)c * a.ts2];
+            const float sw = a.weight[(size_t)b * a.ws0 + (size_t)p * a.ws1 + (size_t)c * a.ws2];
+            const float d = outv[c] - t;
+            e += sw * d * d;
+            gy[c] = 2.f * sw * d * inv3p;
+            if (a.loss_kind == 1) {
+              const float cA = a.stats[(size_t)b * 16 + c], cB = a.stats[(size_t)b * 16 + 4 + c];
+              gy[c] += cA * t - cB * outv[c];
+            }
+          }
+        }
+      }
+      const float es = wave_sum(e);
+      if (lane == 0) a.loss_part[((size_t)tile * 4 + wave) * 16] = es;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (a.act == 1) gy[c] *= (1.f - outv[c] * outv[c]);
+        else if (a.act == 2) gy[c] *= outv[c];
+        if (!a.last_linear) gy[c] *= a.w_hidden * cos_f32(a.w_hidden * ylin[c]);
+        if (!owner) gy[c] = 0.f;
+      }
+    }
+
+    TRACE(6);
+    // =============================== backward ===============================
+    bf16x8 gb[NKS];   // gradient w.r.t. the current layer's pre-activation (g_a), packed
+    bf16x8 ghb[NKS];  // dX result of the current step (g_h), packed as soon as a row block is done
+    // one row block of a dX GEMM -> packed bf16 (only ONE fp32 accumulator tile is ever live)
+    auto dx_rowblock = [&](const char* wb, int rbi, auto& bop, auto nks_tag) {
+      constexpr int NK = decltype(nks_tag)::value;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      acc = gemm_rb<NK>(wb, rbi, bop, acc, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ghb[2 * rbi + (r >> 3)][r & 7] = (__bf16)acc[r];
+    };
+    // g_a = g_h * omega * cos(phase) for one layer's stash
+    auto make_g = [&](const char* sl, float omega) {
+#pragma unroll
+      for (int c = 0; c < NRB * 2; ++c) {
+        const u32x4 w = *(const u32x4*)(sl + c * 4096 + tid16);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          gb[c][2 * d] = (__bf16)((float)ghb[c][2 * d] * omega * __builtin_amdgcn_cosf(phase_lo(w[d])));
+          gb[c][2 * d + 1] = (__bf16)((float)ghb[c][2 * d + 1] * omega * __builtin_amdgcn_cosf(phase_hi(w[d])));
+        }
+      }
+    };
+    // ---- head (step L+1): dW_out += h_L g_y^T ; g_h = W_out^T g_y
+    {
+      bf16x8 gyb[2];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { gyb[0][e] = (__bf16)((e < 3) ? gy[e] : 0.f); gyb[1][e] = (__bf16)0.f; }
+      __syncthreads();  // B1: TA/TB free (previous tile's layer-0 phase done)
+      t_write_b<H, NRB>(TA, hb, wave, hi, j);
+      t_write_b<H, 1>(TB, gyb, wave, hi, j);
+      __syncthreads();  // B2
+      TRACE(7);
+      issue_dma(L + 2 < nstep ? L + 2 : 0);
+      {
+        f32x16 ah[1];
+        acc_zero<1>(ah);
+        float dbh = 0.f;
+        dw_gemm<Pol, H, NRB, 1, DW_HEAD, 1>(TA, TB, ah, dbh, wave, lane);
+        dw_flush<Pol, H, NRB, 1, DW_HEAD, 1>(ah, dbh, dwp + a.p_off_w[L + 1], dwp + a.p_off_b[L + 1], H, first, wave, lane);
+      }
+      const char* wb = smem + ((L + 1) & 1) * GP::WBSZ;
+      const bf16x8 g1[1] = {gyb[0]};
+#pragma unroll
+      for (int rbi = 0; rbi < NRB; ++rbi) dx_rowblock(wb, rbi, g1, std::integral_constant<int, 1>{});
+    }
+    // ---- hidden layers l = L..1 (step k = 2L+2-l)
+#pragma unroll 1
+    for (int l = L; l >= 1; --l) {
+      const int k = 2 * L + 2 - l;
+      TRACE(20 + l);
+      make_g(stash + (size_t)l * G::STASH_LAYER_BYTES, a.w_hidden);
+      if (l == 1) {  // the sixteen AGPR tiles hold dW_2..dW_5; dW_1 = sum g_1 h_0^T is finished by k_reni_dw1
+        char* gp = a.g1 + (size_t)tile * (NKS * 4096);
+#pragma unroll
+        for (int c = 0; c < NKS; ++c) *(bf16x8*)(gp + c * 4096 + tid16) = gb[c];
+      }
+      TRACE(30 + l);
+      __syncthreads();  // B1: every wave finished the previous step's LDS reads
+      TRACE(40 + l);
+      t_write_b<H, NRB>(TA, gb, wave, hi, j);
+      TRACE(80 + l);
+      {  // h_{l-1} = sin(phase_{l-1}) straight into the transposed image (needed as dW_l's column operand)
+        const char* sp = stash + (size_t)(l - 1) * G::STASH_LAYER_BYTES;
+#pragma unroll
+        for (int c = 0; c < NRB * 2; ++c) {
+          const u32x4 w = *(const u32x4*)(sp + c * 4096 + tid16);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const int r = (c & 1) * 8 + 2 * d;
+            const int f0 = 32 * (c >> 1) + rowmap(r, hi), f1 = 32 * (c >> 1) + rowmap(r + 1, hi);
+            *(__bf16*)(TB + f0 * G::T_ROWB + (wave * 32 + j) * 2) = (__bf16)__builtin_amdgcn_sinf(phase_lo(w[d]));
+            *(__bf16*)(TB + f1 * G::T_ROWB + (wave * 32 + j) * 2) = (__bf16)__builtin_amdgcn_sinf(phase_hi(w[d]));
+          }
+        }
+      }
+      TRACE(50 + l);
+      __syncthreads();  // B2
+      TRACE(60 + l);
+      if (k + 1 < nstep) issue_dma(k + 1);
+      else if (tile + (int)gridDim.x < a.n_tiles) issue_dma(0);
+      switch (l) {  // one static register set per layer
+        case 5: dw_gemm<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, pacc[4], pdb[4], wave, lane); break;
+        case 4: dw_gemm<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, pacc[3], pdb[3], wave, lane); break;
+        case 3: dw_gemm<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, pacc[2], pdb[2], wave, lane); break;
+        case 2: dw_gemm<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, pacc[1], pdb[1], wave, lane); break;
+        default: break;  // layer 1: handled by k_reni_dw1 from the g_1 stream stored below
+      }
+      TRACE(70 + l);
+      const char* wb = smem + (k & 1) * GP::WBSZ;
+#pragma unroll
+      for (int rbi = 0; rbi < NRB; ++rbi) dx_rowblock(wb, rbi, gb, std::integral_constant<int, NKS>{});
+    }
+    TRACE(8);
+    // ---- layer 0: dA (per tile) = g_0 (x_hi | x_lo)^T
+    {
+      make_g(stash, a.w_first);
+      bf16x8 xcb[2];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { xcb[0][e] = (__bf16)0.f; xcb[1][e] = (__bf16)0.f; }
+      if (hi == 0) {
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) { xcb[0][k2] = xh[k2]; xcb[0][4 + k2] = xl[k2]; }
+      } else {
+        xcb[0][0] = (__bf16)1.f;
+      }
+      __syncthreads();
+      t_write_b<H, NRB>(TA, gb, wave, hi, j);
+      t_write_b<H, 1>(TB, xcb, wave, hi, j);
+      __syncthreads();
+      f32x16 accA[1];
+      acc_zero<1>(accA);
+      float dummy = 0.f;
+      dw_gemm<Pol, H, NRB, 1, DW_L0, 1>(TA, TB, accA, dummy, wave, lane);
+      dw_flush<Pol, H, NRB, 1, DW_L0, 1>(accA, 0.f, a.dA_part + (size_t)tile * H * 16, nullptr, 16, true, wave, lane);
+    }
+    TRACE(9);
+    first = false;
+  }
+  // ---- the only write of the hidden-layer weight-gradient partials: once per workgroup per launch
+#pragma unroll
+  for (int l = 2; l <= PMAX; ++l)
+    if (l <= L)
+      dw_flush<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H>(pacc[l - 1], pdb[l - 1], dwp + a.p_off_w[l], dwp + a.p_off_b[l], H, true, wave, lane);
+}
+template __global__ void k_reni_train_bf16<128>(const MainArgs);
+
+// dW_1 / db_1 for the persistent training path: K = samples GEMM of the stored g_1 stream (bf16,
+// D layout, written by k_reni_train_bf16) with h_0 = sin(w0 (A_b x)) recomputed from the directions.
+// Persistent workgroups; the 128 x 128 accumulator stays in registers over all of a workgroup's tiles.
+template <int H>
+__global__ void __launch_bounds__(256, 2) k_reni_dw1(const MainArgs a) {
+  using Pol = PolBF16;
+  using G = Geo<Pol, H>;
+  constexpr int NRB = G::NRB, NKS = G::NKS;
+  constexpr int MYB_H = (NRB * NRB + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const TA = smem;
+  char* const TB = smem + G::T_BYTES_AL;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, hi = lane >> 5, j = lane & 31;
+  f32x16 acc[MYB_H];
+  acc_zero<MYB_H>(acc);
+  float db = 0.f;
+  const float sc_first = a.w_first * 0.15915494309189535f;
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int b = tile / a.tiles_per_image;
+    const int p = (tile - b * a.tiles_per_image) * 128 + wave * 32 + j;
+    const bool valid = p < a.P;
+    float x[5];
+    {
+      const float* dp = a.D + (size_t)b * a.d_bstride + (size_t)(valid ? p : 0) * 3;
+      x[0] = dp[0]; x[1] = dp[1]; x[2] = dp[2];
+      x[3] = sqrtf(x[0] * x[0] + x[2] * x[2]);
+      x[4] = 1.f;
+    }
+    __bf16 xh[5], xl[4];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) xh[k] = (__bf16)x[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xl[k] = (__bf16)(x[k] - (float)xh[k]);
+    bf16x8 hb[NKS], gb[NKS];
+    {
+      const char* gp = a.g1 + (size_t)tile * (NKS * 4096);
+#pragma unroll
+      for (int c = 0; c < NKS; ++c) gb[c] = *(const bf16x8*)(gp + c * 4096 + tid * 16);
+    }
+    {
+      const float* Ab = a.Apre + (size_t)b * H * 8;
+      bf16x8 bop;
+      if (hi == 0) { bop[0] = xh[0]; bop[1] = xh[1]; bop[2] = xh[2]; bop[3] = xh[3]; bop[4] = xh[4]; bop[5] = xh[0]; bop[6] = xh[1]; bop[7] = xh[2]; }
+      else { bop[0] = xh[3]; bop[1] = xh[4]; bop[2] = xl[0]; bop[3] = xl[1]; bop[4] = xl[2]; bop[5] = xl[3]; bop[6] = (__bf16)0.f; bop[7] = (__bf16)0.f; }
+#pragma unroll
+      for (int rbo = 0; rbo < NRB; ++rbo) {
+        const f32x4 lo4 = *(const f32x4*)(Ab + (32 * rbo + j) * 8);
+        const float a4 = Ab[(32 * rbo + j) * 8 + 4];
+        const float A5[5] = {lo4[0], lo4[1], lo4[2], lo4[3], a4};
+        __bf16 Ah[5], Al[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { Ah[k] = (__bf16)A5[k]; Al[k] = (__bf16)(A5[k] - (float)Ah[k]); }
+        bf16x8 aop;
+        if (hi == 0) { aop[0] = Ah[0]; aop[1] = Ah[1]; aop[2] = Ah[2]; aop[3] = Ah[3]; aop[4] = Ah[4]; aop[5] = Al[0]; aop[6] = Al[1]; aop[7] = Al[2]; }
+        else { aop[0] = Al[3]; aop[1] = Al[4]; aop[2] = Ah[0]; aop[3] = Ah[1]; aop[4] = Ah[2]; aop[5] = Ah[3]; aop[6] = (__bf16)0.f; aop[7] = (__bf16)0.f; }
+        f32x16 a0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a0[r] = 0.f;
+        a0 = PolBF16::mfma(aop, bop, a0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          // same phase quantisation as the training kernel's stash, so h_0 is bit-identical to what it used
+          const float th = __builtin_amdgcn_fractf(a0[r] * sc_first);
+          const unsigned q = ((unsigned)(th * 65536.f + 0.5f)) & 0xffffu;
+          hb[2 * rbo + (r >> 3)][r & 7] = (__bf16)__builtin_amdgcn_sinf(__uint_as_float((q << 7) | 0x3f800000u));
+        }
+      }
+    }
+    __syncthreads();
+    t_write_b<H, NRB>(TA, gb, wave, hi, j);
+    t_write_b<H, NRB>(TB, hb, wave, hi, j);
+    __syncthreads();
+    dw_gemm<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H>(TA, TB, acc, db, wave, lane);
+  }
+  float* const dwp = a.dwp + (size_t)blockIdx.x * a.dwp_per_wg;
+  dw_flush<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H>(acc, db, dwp + a.p_off_w[1], dwp + a.p_off_b[1], H, true, wave, lane);
+}
+template __global__ void k_reni_dw1<128>(const MainArgs);
 
 // ------------------------------------------------------------------------------------------
 // prologue: per-image constant input columns and the affine map A_b
@@ -708,6 +1343,7 @@ __global__ void __launch_bounds__(256) k_pack(const PackArgs a) {
     for (int i = threadIdx.x; i < d.bias_n_pad; i += 256) bo[i] = (i < d.bias_n) ? a.params[d.bias_src + i] : 0.f;
   }
 }
+#ifndef RENI_ONLY_TRAIN
 template __global__ void k_pack<PolF32>(const PackArgs);
 template __global__ void k_pack<PolBF16>(const PackArgs);
 
@@ -916,6 +1552,18 @@ __global__ void k_probe(float* outD, int which) {
   for (int r = 0; r < 16; ++r) outD[rowmap(r, hi) * 32 + j] = acc[r];
 }
 
+// probe of ds_read_b64_tr_b16: LDS holds u16 element i = i; lane l reads at byte address 8*l (mode 0) or
+// at a caller-given per-lane byte address (mode 1); out[l*4 + e] = element e returned to lane l
+__global__ void k_probe_tr(unsigned short* out, const int* lane_addr, int mode) {
+  __shared__ __attribute__((aligned(16))) unsigned short lds[4096];
+  for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = (unsigned short)i;
+  __syncthreads();
+  const unsigned addr = (unsigned)(size_t)lds + (mode == 0 ? threadIdx.x * 8 : lane_addr[threadIdx.x]);
+  unsigned long long v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  for (int e = 0; e < 4; ++e) out[threadIdx.x * 4 + e] = (unsigned short)(v >> (16 * e));
+}
+
 // explicit instantiations of the fused kernel
 #define RENI_INST(POL, HH)                                                     \
   template __global__ void k_reni_main<POL, HH, MODE_FWD>(const MainArgs);     \
@@ -927,7 +1575,10 @@ RENI_INST(PolF32, 128)
 RENI_INST(PolBF16, 32)
 RENI_INST(PolBF16, 64)
 RENI_INST(PolBF16, 128)
+#endif  // RENI_ONLY_TRAIN
 
 }  // namespace reni
 
+#ifndef RENI_ONLY_TRAIN
 #include "reni_capi.inc"
+#endif
