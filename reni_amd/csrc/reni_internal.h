@@ -71,6 +71,8 @@ struct TailArgs {
   const float* W0;
   const float* Z;
   const float* xconst;
+  float* mcol;  // [B][F_in] scratch: W0^T g_c
+  float* ucol;  // [B][ND][3] scratch: W_ip^T dA[:,xyz]
   float* dZ;
   float* dW0;
   float* db0;

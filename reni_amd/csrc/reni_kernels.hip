@@ -1253,6 +1253,7 @@ template __global__ void k_reni_dw1<128>(const MainArgs);
 // xconst[b][col] = value of input column col if it is constant over the image, else 0
 // A[b][h][0..4] = coefficients of (dx, dy, dz, r, 1)
 __global__ void __launch_bounds__(256) k_prep_image(const PrepArgs a) {
+  // grid (B, H/8): every block rebuilds the image's constant columns in LDS (cheap) and does 8 rows
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xc = (float*)smem;  // F_in
   const int b = blockIdx.x, tid = threadIdx.x, nd = a.nd, F = a.F_in;
@@ -1278,11 +1279,11 @@ __global__ void __launch_bounds__(256) k_prep_image(const PrepArgs a) {
       if (c1 >= 0) val = z[c1];
     }
     xc[col] = val;
-    a.xconst[(size_t)b * F + col] = val;
+    if (blockIdx.y == 0) a.xconst[(size_t)b * F + col] = val;
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
-  for (int h = wave; h < a.H; h += 4) {
+  for (int h = blockIdx.y * 8 + wave; h < min(a.H, (int)blockIdx.y * 8 + 8); h += 4) {
     const float* w = a.W0 + (size_t)h * F;
     float c = 0.f, ux = 0.f, uy = 0.f, uz = 0.f;
     for (int col = lane; col < F; col += 64) {
@@ -1355,33 +1356,63 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float* part, size
                                                           float* dparams, int lo, int n) {
   const int i = lo + blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float s = 0.f;
-  for (int w = 0; w < nwg; ++w) s += part[(size_t)w * per_wg + i];
-  dparams[i] = s;
+  // four interleaved partial sums (fixed order -> deterministic) keep four loads in flight
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int w = 0;
+  for (; w + 3 < nwg; w += 4) {
+    s0 += part[(size_t)w * per_wg + i];
+    s1 += part[(size_t)(w + 1) * per_wg + i];
+    s2 += part[(size_t)(w + 2) * per_wg + i];
+    s3 += part[(size_t)(w + 3) * per_wg + i];
+  }
+  for (; w < nwg; ++w) s0 += part[(size_t)w * per_wg + i];
+  dparams[i] = (s0 + s1) + (s2 + s3);
 }
 
-// per image: dA[b][h][k] = sum over the image's tiles (x_hi part + x_lo part); mse[b]
-__global__ void __launch_bounds__(256) k_reduce_tiles(const float* dA_part, const float* loss_part,
-                                                      int tiles_per_image, int H, int P, float* dA,
-                                                      float* img_loss, int have_dA) {
-  const int b = blockIdx.x;
+// Per-image reduction of the per-tile partials, two fixed-order stages.
+// stage A: grid (B, nchunk): sum RT_CHUNK consecutive tiles -> part2[b][chunk][H*8 + 16]
+//          (dA[h][k] = x_hi part + x_lo part for k < 5; 16 loss/statistics slots summed over tiles and waves)
+// stage B: grid B: sum the chunks -> dA[b][h][8], img_loss[b][16]
+constexpr int RT_CHUNK = 16;
+__global__ void __launch_bounds__(256) k_reduce_tiles_a(const float* dA_part, const float* loss_part,
+                                                        int tiles_per_image, int H, float* part2, int have_dA) {
+  const int b = blockIdx.x, ch = blockIdx.y, nch = gridDim.y;
+  const int t0 = ch * RT_CHUNK, t1 = min(t0 + RT_CHUNK, tiles_per_image);
+  float* out = part2 + ((size_t)b * nch + ch) * (H * 8 + 16);
   if (have_dA) {
     for (int i = threadIdx.x; i < H * 8; i += 256) {
       const int h = i >> 3, k = i & 7;
       float s = 0.f;
       if (k < 5) {
-        for (int t = 0; t < tiles_per_image; ++t) {
+        for (int t = t0; t < t1; ++t) {
           const float* q = dA_part + ((size_t)(b * tiles_per_image + t) * H + h) * 16;
           s += q[k] + ((k < 4) ? q[8 + k] : 0.f);
         }
       }
-      dA[((size_t)b * H + h) * 8 + k] = s;
+      out[i] = s;
     }
   }
-  // loss partial sums: 16 slots per (tile, wave); slot 0 = weighted squared error, 1..9 = stats
   if (threadIdx.x < 16) {
     float s = 0.f;
-    for (int t = 0; t < tiles_per_image * 4; ++t) s += loss_part[((size_t)b * tiles_per_image * 4 + t) * 16 + threadIdx.x];
+    for (int t = t0 * 4; t < t1 * 4; ++t) s += loss_part[((size_t)b * tiles_per_image * 4 + t) * 16 + threadIdx.x];
+    out[H * 8 + threadIdx.x] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_reduce_tiles_b(const float* part2, int nch, int H, float* dA,
+                                                        float* img_loss, int have_dA) {
+  const int b = blockIdx.x;
+  const float* in = part2 + (size_t)b * nch * (H * 8 + 16);
+  if (have_dA) {
+    for (int i = threadIdx.x; i < H * 8; i += 256) {
+      float s = 0.f;
+      for (int c = 0; c < nch; ++c) s += in[(size_t)c * (H * 8 + 16) + i];
+      dA[(size_t)b * H * 8 + i] = s;
+    }
+  }
+  if (threadIdx.x < 16) {
+    float s = 0.f;
+    for (int c = 0; c < nch; ++c) s += in[(size_t)c * (H * 8 + 16) + H * 8 + threadIdx.x];
     img_loss[(size_t)b * 16 + threadIdx.x] = s;
   }
 }
@@ -1435,27 +1466,43 @@ __global__ void k_finalize_loss(const float* img_loss, const float* stats, const
   }
 }
 
-// per image: m[col] = W0[:,col]^T g (g = constant-column gradient dA[:,4], or the direction
-// columns for the inner-product block), then assemble dZ
-__global__ void __launch_bounds__(256) k_tail_dz(const TailArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int F = a.F_in, nd = a.nd, H = a.H, b = blockIdx.x, tid = threadIdx.x;
-  float* m = (float*)smem;   // F : W0^T g_c
-  float* u = m + F;          // 3*nd : W_ip^T dU (x,y,z components)
-  float* dAs = u + 3 * nd;   // H*8
-  for (int i = tid; i < H * 8; i += 256) dAs[i] = a.dA[(size_t)b * H * 8 + i];
-  __syncthreads();
-  for (int col = tid; col < F; col += 256) {
-    float s = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int h = 0; h < H; ++h) {
+// per image: m[col] = W0[:,col]^T g_c (g_c = constant-column gradient dA[:,4]) and, for the inner-product
+// block, u[col][xyz] = W_ip[:,col]^T dA[:,xyz].   grid (B, ceil(F/64)); 4 row groups x 64 columns per block
+__global__ void __launch_bounds__(256) k_tail_m(const TailArgs a) {
+  __shared__ float red[4][64][4];
+  const int F = a.F_in, nd = a.nd, H = a.H, b = blockIdx.x;
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + c;
+  float s = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+  if (col < F) {
+    const float* dAb = a.dA + (size_t)b * H * 8;
+    const int h0 = rg * (H / 4), h1 = h0 + H / 4;
+    for (int h = h0; h < h1; ++h) {
       const float w = a.W0[(size_t)h * F + col];
-      s += w * dAs[h * 8 + 4];
-      if (col < nd) { sx += w * dAs[h * 8]; sy += w * dAs[h * 8 + 1]; sz += w * dAs[h * 8 + 2]; }
+      const float* q = dAb + h * 8;
+      s += w * q[4];
+      if (col < nd) { sx += w * q[0]; sy += w * q[1]; sz += w * q[2]; }
     }
-    m[col] = s;
-    if (col < nd) { u[col * 3] = sx; u[col * 3 + 1] = sy; u[col * 3 + 2] = sz; }
   }
+  red[rg][c][0] = s; red[rg][c][1] = sx; red[rg][c][2] = sy; red[rg][c][3] = sz;
   __syncthreads();
+  if (rg == 0 && col < F) {
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = (red[0][c][k] + red[1][c][k]) + (red[2][c][k] + red[3][c][k]);
+    a.mcol[(size_t)b * F + col] = t[0];
+    if (col < nd) {
+      float* u = a.ucol + ((size_t)b * nd + col) * 3;
+      u[0] = t[1]; u[1] = t[2]; u[2] = t[3];
+    }
+  }
+}
+
+// assemble dZ from m / u.  grid B
+__global__ void __launch_bounds__(256) k_tail_dz(const TailArgs a) {
+  const int F = a.F_in, nd = a.nd, b = blockIdx.x, tid = threadIdx.x;
+  const float* m = a.mcol + (size_t)b * F;
+  const float* u = a.ucol + (size_t)b * nd * 3;
   const float* z = a.Z + (size_t)b * nd * 3;
   for (int t = tid; t < nd * 3; t += 256) {
     const int i = t / 3, k = t - 3 * i;
