@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "reni_internal.h"
 
@@ -315,18 +316,46 @@ enum { DW_HIDDEN = 0, DW_HEAD = 1, DW_L0 = 2 };
 // persistent training kernel needs twenty-odd live tiles, so it pins them by hand.  Operands come
 // straight from ds_read (the compiler's s_waitcnt covers them) and the accumulator is only ever
 // touched by these statements, so no MFMA hazard crosses the asm boundary (cdna guide, 5.7).
-// hipcc neither pads hazards inside an asm statement nor knows that the statement is an MFMA, so the
-// wait states are part of the string: `s_nop 4` in front covers a compiler-generated VALU / v_accvgpr_write
-// of an operand just before (e.g. a reload of a spilled tile); LAST = the final MFMA of a chain on this
-// tile is followed by 20 wait states so that a compiler read of the result (v_accvgpr_read for a spill,
-// the final flush) never overtakes the 8-pass XDL write-back.
-template <bool LAST>
-DEV void mfma_bf16_pin_a(f32x16& acc, bf16x8 a, bf16x8 b) {
+// ---- hand-owned AGPRs ------------------------------------------------------------------------------
+// The persistent training kernel owns ALL 256 AGPRs as sixteen literal 32x32 fp32 tiles a[16t:16t+15]
+// (t = 4*(layer-2) + column block): the dW accumulators of hidden layers 2..5.  The compiler never sees
+// them as values -- every statement that touches them names the registers in its text and lists all AGPRs
+// as clobbers (which also makes the kernel descriptor allocate them); the library is built with
+// -amdgpu-spill-vgpr-to-agpr=0 and every MFMA of that kernel is an asm statement, so no compiler-generated
+// instruction ever reads or writes an AGPR (checked on the emitted ISA by tests/test_build_audit.py).
+//
+// hipcc neither pads hazards inside an asm statement nor knows that the statement is an MFMA, so the wait
+// states are part of the string: `s_nop 4` in front covers a VALU write of an operand just before; LAST =
+// the final MFMA of a chain is followed by 20 wait states so that a read of the result never overtakes the
+// 8-pass XDL write-back.
+#define RENI_A10(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+#define RENI_AGPR_ALL                                                                                       \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", RENI_A10(1), RENI_A10(2), RENI_A10(3),         \
+      RENI_A10(4), RENI_A10(5), RENI_A10(6), RENI_A10(7), RENI_A10(8), RENI_A10(9), RENI_A10(10),            \
+      RENI_A10(11), RENI_A10(12), RENI_A10(13), RENI_A10(14), RENI_A10(15), RENI_A10(16), RENI_A10(17),      \
+      RENI_A10(18), RENI_A10(19), RENI_A10(20), RENI_A10(21), RENI_A10(22), RENI_A10(23), RENI_A10(24),      \
+      "a250", "a251", "a252", "a253", "a254", "a255"
+
+template <int T, bool LAST>
+DEV void mfma_bf16_agpr_tile(bf16x8 a, bf16x8 b) {
   if constexpr (LAST)
-    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+a"(acc) : "v"(a), "v"(b));
+    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]\n\ts_nop 15\n\ts_nop 3"
+                 :: "v"(a), "v"(b), "i"(16 * T), "i"(16 * T + 15) : RENI_AGPR_ALL);
   else
-    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]"
+                 :: "v"(a), "v"(b), "i"(16 * T), "i"(16 * T + 15) : RENI_AGPR_ALL);
 }
+template <int N>
+DEV void agpr_zero_one() { asm volatile("v_accvgpr_write_b32 a[%c0], 0" :: "i"(N) : RENI_AGPR_ALL); }
+template <int... I>
+DEV void agpr_zero_seq(std::integer_sequence<int, I...>) { (agpr_zero_one<I>(), ...); }
+template <int N>
+DEV float agpr_read_one() { float x; asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(N)); return x; }
+template <int T, int... R>
+DEV f32x16 agpr_read_tile_seq(std::integer_sequence<int, R...>) { f32x16 v = {agpr_read_one<16 * T + R>()...}; return v; }
+template <int T>
+DEV f32x16 agpr_read_tile() { return agpr_read_tile_seq<T>(std::make_integer_sequence<int, 16>{}); }
+
 template <bool LAST>
 DEV void mfma_bf16_pin_v(f32x16& acc, bf16x8 a, bf16x8 b) {
   if constexpr (LAST)
@@ -372,14 +401,8 @@ DEV void dw_gemm(const char* TA, const char* TB, f32x16 (&acc)[MYB], float& dbac
         const int blk = wave + 4 * m;
         Frag fa = t_read<Pol, H, NBR>(TA, blk % NBR, ks, j, hi);
         Frag fb = t_read<Pol, H, NBC>(TB, blk / NBR, ks, j, hi);
-        constexpr bool kLast = false;
-        if (ks == NKS_T - 1 && m == MYB - 1) {
-          if constexpr (PIN == 1) mfma_bf16_pin_a<true>(acc[m], fa, fb);
-          else mfma_bf16_pin_v<true>(acc[m], fa, fb);
-        } else {
-          if constexpr (PIN == 1) mfma_bf16_pin_a<kLast>(acc[m], fa, fb);
-          else mfma_bf16_pin_v<kLast>(acc[m], fa, fb);
-        }
+        if (ks == NKS_T - 1 && m == MYB - 1) mfma_bf16_pin_v<true>(acc[m], fa, fb);
+        else mfma_bf16_pin_v<false>(acc[m], fa, fb);
         if (KIND == DW_HIDDEN && m == 0 && (wave / NBR) == 0) dbacc += frag_sum<Pol>(fa);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -441,24 +464,6 @@ DEV void dw_flush(const f32x16 (&acc)[MYB], float dbacc, float* dst_w, float* ds
   }
 }
 
-// transposition round(s) + K = samples GEMM into caller-owned accumulators (no flush)
-template <class Pol, int H, int NBR, int NBC, int KIND, int MYB, int PIN>
-DEV void dw_accum(char* TA, char* TB, const float (&rows)[NBR][16], const float (&cols)[NBC][16],
-                  f32x16 (&acc)[MYB], float& dbacc, int wave, int lane) {
-  constexpr int NROUND = 4 / Pol::ROUND_WAVES;
-  const int hi = lane >> 5, j = lane & 31;
-#pragma unroll 1
-  for (int round = 0; round < NROUND; ++round) {
-    __syncthreads();
-    if (wave / Pol::ROUND_WAVES == round) {
-      t_write<Pol, H, NBR>(TA, rows, wave % Pol::ROUND_WAVES, hi, j);
-      t_write<Pol, H, NBC>(TB, cols, wave % Pol::ROUND_WAVES, hi, j);
-    }
-    __syncthreads();
-    dw_gemm<Pol, H, NBR, NBC, KIND, MYB, PIN>(TA, TB, acc, dbacc, wave, lane);
-  }
-}
-
 // dM[row-feature][col-feature] (+)= sum over the tile's 128 samples rows[.][s] * cols[.][s].
 //   DW_HIDDEN: rows = g_a (layer outputs), cols = h_{l-1}; flushed to dW_l [out][in] and db_l
 //   DW_HEAD  : rows = h_L, cols = g_y (3 real);            flushed to dW_out[c][feature], db_out
@@ -501,23 +506,10 @@ DEV void dw_phase(char* TA, char* TB, const float (&rows)[NBR][16], const float 
 // ------------------------------------------------------------------------------------------
 enum { MODE_FWD = 0, MODE_STATS = 1, MODE_FWD_BWD = 2 };
 
-// PERSIST (bf16 training only, L <= PMAX hidden layers): the dW_l accumulators of every hidden layer
-// live in registers for the workgroup's whole tile loop -- 4 layers pinned to the AGPR half of the
-// register file, the fifth to VGPRs -- and are written once per launch.  One workgroup per CU
-// (one wave per SIMD, up to 512 registers).  The per-tile "+=" flush of the generic form was 65 % of
-// its run time (profiles/r01_b_ablation.md).
-template <class Pol, int H, int MODE, bool PERSIST = false>
-__global__ void __launch_bounds__(256, (PERSIST ? 1 : Pol::WPS)) k_reni_main(const MainArgs a) {
+template <class Pol, int H, int MODE>
+__global__ void __launch_bounds__(256, Pol::WPS) k_reni_main(const MainArgs a) {
   using G = Geo<Pol, H>;
   constexpr int NRB = G::NRB;
-  constexpr int MYB_H = (NRB * NRB + 3) / 4;
-  constexpr int PMAX = 5;
-  f32x16 pacc[PERSIST ? PMAX : 1][MYB_H];
-  float pdb[PERSIST ? PMAX : 1];
-  if constexpr (PERSIST) {
-#pragma unroll
-    for (int l = 0; l < PMAX; ++l) { acc_zero<MYB_H>(pacc[l]); pdb[l] = 0.f; }
-  }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const WB = smem;
   char* const TA = smem;  // aliases WB: the weight image is dead while a dW phase runs
@@ -708,18 +700,7 @@ __global__ void __launch_bounds__(256, (PERSIST ? 1 : Pol::WPS)) k_reni_main(con
         float hp[NRB][16];
         act_replay<Pol, NRB, 1>(hp, nullptr, (l - 1 == 0) ? a.w_first : a.w_hidden, 0.f,
                                 stash + (size_t)(l - 1) * G::STASH_LAYER_BYTES, tid);
-        if constexpr (PERSIST) {
-          // one static register set per layer; layers 2..5 in AGPRs, layer 1 in VGPRs
-          switch (l) {
-            case 5: dw_accum<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, g, hp, pacc[4], pdb[4], wave, lane); break;
-            case 4: dw_accum<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, g, hp, pacc[3], pdb[3], wave, lane); break;
-            case 3: dw_accum<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, g, hp, pacc[2], pdb[2], wave, lane); break;
-            case 2: dw_accum<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, g, hp, pacc[1], pdb[1], wave, lane); break;
-            default: dw_accum<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 2>(TA, TB, g, hp, pacc[0], pdb[0], wave, lane); break;
-          }
-        } else {
-          dw_phase<Pol, H, NRB, NRB, DW_HIDDEN>(TA, TB, g, hp, dwp + a.p_off_w[l], dwp + a.p_off_b[l], H, first, wave, lane, a.dbg);
-        }
+        dw_phase<Pol, H, NRB, NRB, DW_HIDDEN>(TA, TB, g, hp, dwp + a.p_off_w[l], dwp + a.p_off_b[l], H, first, wave, lane, a.dbg);
       }
       __syncthreads();
       if (!(a.dbg & 32)) stage_to_lds(WB, a.wimg + a.bwd_off[l], G::IMG_HID, tid);
@@ -749,27 +730,9 @@ __global__ void __launch_bounds__(256, (PERSIST ? 1 : Pol::WPS)) k_reni_main(con
     }
     first = false;
   }
-  if constexpr (PERSIST) {
-    // the only write of the hidden-layer weight-gradient partials: once per workgroup per launch
-#pragma unroll
-    for (int l = 1; l <= PMAX; ++l)
-      if (l <= L)
-        dw_flush<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H>(pacc[l - 1], pdb[l - 1], dwp + a.p_off_w[l], dwp + a.p_off_b[l], H, true, wave, lane);
-  }
 }
 
-// ==========================================================================================
-// bf16 TRAINING kernel with register-persistent weight-gradient accumulators
-// ==========================================================================================
-// Same arithmetic as k_reni_main<PolBF16, H, MODE_FWD_BWD>, different schedule:
-//   * exactly LP hidden layers (compile time): the dW_l accumulators (LP x H x H fp32 = 320 KB for
-//     5 x 128^2, 62 % of a CU's register file) live in AGPRs/VGPRs across the workgroup's whole
-//     tile loop and are written ONCE per launch -- the generic kernel's per-tile "+=" flush of the
-//     partials was 65 % of its run time (profiles/r01_b_ablation.md);
-//   * one workgroup (4 waves, one per SIMD, up to 512 registers each) per CU;
-//   * activations travel between layers as packed bf16 MFMA operands (no fp32 copies);
-//   * weight images are double-buffered in LDS and fetched one step ahead by LDS-DMA
-//     (global_load_lds), so a step has one barrier (forward) or two (backward), no staging stall.
+// ---- helpers of the bf16 training path ---------------------------------------------------------
 template <int N, class F>
 DEV void static_for_down(F&& f) {
   if constexpr (N >= 1) {
@@ -782,7 +745,7 @@ template <int H>
 struct GeoP {
   using G = Geo<PolBF16, H>;
   static constexpr int WBSZ = (G::IMG_HID + G::BIAS_HID + 1023) & ~1023;  // DMA moves 1 KB pieces
-  static constexpr int TSZ = G::T_BYTES_AL;
+  static constexpr int TSZ = 128 * 256;  // sample-major image, see ts_write / ts_read
   static constexpr int LDS_BYTES = 2 * WBSZ + 2 * TSZ;
 };
 
@@ -802,12 +765,16 @@ DEV void dma_image(char* lds_dst, const char* gsrc, int wave, int lane16) {
 
 // acc[rbo] (+)= W-image[rbo] . bop   (row-block-outer order so the caller's per-row-block epilogue
 // overlaps the next row block's MFMAs)
+// All MFMAs of the training kernel name their accumulator's register file explicitly: the 256 AGPRs belong
+// to the sixteen persistent dW tiles, so the chain GEMMs accumulate in VGPRs ("+v").  The last MFMA of a
+// chain carries the wait states the following VALU reads of the result need.
 template <int NKS>
 DEV f32x16 gemm_rb(const char* wb, int rbo, const bf16x8 (&bop)[NKS], f32x16 acc, int lane) {
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
     bf16x8 a = *(const bf16x8*)(wb + ((rbo * NKS + ks) * 64 + lane) * 16);
-    acc = PolBF16::mfma(a, bop[ks], acc);
+    if (ks == NKS - 1) mfma_bf16_pin_v<true>(acc, a, bop[ks]);
+    else mfma_bf16_pin_v<false>(acc, a, bop[ks]);
   }
   return acc;
 }
@@ -826,6 +793,106 @@ DEV void t_write_b(char* T, const bf16x8 (&xb)[2 * NB], int wave, int hi, int j)
 DEV float phase_lo(unsigned w) { return __uint_as_float(((w & 0xffffu) << 7) | 0x3f800000u); }
 DEV float phase_hi(unsigned w) { return __uint_as_float(((w >> 9) & 0x007fff80u) | 0x3f800000u); }
 
+// ---- sample-major transposition image of the bf16 training path (H = 128) --------------------------
+// Row s (one of the tile's 128 samples) = 256 B = 32 pieces of 8 B; logical piece c holds features
+// 4c..4c+3 of that sample.  Pieces are stored at c ^ tswz(s), which makes both the 8-byte writes (a lane
+// owns a sample) and the ds_read_b64_tr_b16 transpose reads (a lane ends up owning a feature) free of LDS
+// bank conflicts.  A fragment read returns, to lane l, feature 32*blk + (l & 31) for
+// samples 16*ks + 8*(l >> 5) + 0..7 -- the MFMA operand layout with K = samples.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr int TS_BYTES = 128 * 256;
+DEV int tswz(int s) { return ((s & 1) << 4) | ((s & 2) << 2) | ((s & 1) << 2) | ((s & 8) >> 2) | ((s & 4) >> 2); }
+
+// write NB 32-feature blocks of packed bf16 (D layout) for sample s
+template <int NB>
+DEV void ts_write(char* T, const bf16x8 (&xb)[2 * NB], int s, int hi) {
+  char* row = T + s * 256;
+  const int x = tswz(s);
+#pragma unroll
+  for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const u32x4 w = __builtin_bit_cast(u32x4, xb[2 * rb + (u >> 1)]);
+      const u32x2 h = (u & 1) ? u32x2{w[2], w[3]} : u32x2{w[0], w[1]};
+      *(u32x2*)(row + (((8 * rb + 2 * u + hi) ^ x) << 3)) = h;
+    }
+}
+// the two 8-byte halves of one bf16x8 (features 8*(c&1).. of block c>>1, i.e. chunk index c) for sample s
+DEV void ts_write_chunk(char* T, bf16x8 v, int c, int s, int hi) {
+  char* row = T + s * 256;
+  const int x = tswz(s);
+  const u32x4 w = __builtin_bit_cast(u32x4, v);
+  const int rb = c >> 1, u0 = 2 * (c & 1);
+  *(u32x2*)(row + (((8 * rb + 2 * u0 + hi) ^ x) << 3)) = u32x2{w[0], w[1]};
+  *(u32x2*)(row + (((8 * rb + 2 * (u0 + 1) + hi) ^ x) << 3)) = u32x2{w[2], w[3]};
+}
+// per-lane byte offsets (block 0, k-step 0) of the two transpose reads that make one fragment
+DEV void ts_lane_offsets(int lane, int (&a0)[2]) {
+  const int khi = lane >> 5, g = (lane >> 4) & 1, u = lane & 15;
+  const int s0 = (u >> 2) & 1, s1 = (u >> 3) & 1;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int x = (s0 << 4) | (s1 << 3) | (s0 << 2) | (khi << 1) | q;
+    const int phys = ((4 * g + (u & 3)) ^ (x & 7)) | ((x >> 3) << 3);
+    a0[q] = (8 * khi + 4 * q + (u >> 2)) * 256 + phys * 8;
+  }
+}
+DEV bf16x8 ts_read(const char* T, const int (&a0)[2], int blk, int ks) {
+  typedef __attribute__((address_space(3))) s16x4* lp;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(T + ((a0[0] ^ (blk << 6)) + ks * 4096)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(T + ((a0[1] ^ (blk << 6)) + ks * 4096)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// K = samples GEMM from sample-major images: rows block(s) x cols block(s), 128 samples.
+// Wave w owns row block w (NBR == 4) and all NBC column blocks.  PIN: 0 compiler-allocated accumulator,
+// 2 accumulator pinned to VGPRs (asm MFMA).
+template <int NBC, int KIND, int PIN>
+DEV void dw_gemm_s(const char* TA, const char* TB, f32x16 (&acc)[NBC], float& dbacc, int wave, int lane) {
+  int a0[2];
+  ts_lane_offsets(lane, a0);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const bf16x8 fa = ts_read(TA, a0, wave, ks);
+#pragma unroll
+    for (int m = 0; m < NBC; ++m) {
+      const bf16x8 fb = ts_read(TB, a0, m, ks);
+      if constexpr (PIN == 2) {
+        if (ks == 7 && m == NBC - 1) mfma_bf16_pin_v<true>(acc[m], fa, fb);
+        else mfma_bf16_pin_v<false>(acc[m], fa, fb);
+      } else {
+        acc[m] = PolBF16::mfma(fa, fb, acc[m]);
+      }
+      if (KIND == DW_HEAD && m == 0 && wave == 0) dbacc += frag_sum<PolBF16>(fb);
+    }
+    if (KIND == DW_HIDDEN) dbacc += frag_sum<PolBF16>(fa);
+    if constexpr (PIN != 0) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// hidden-layer dW into the hand-owned AGPR tiles BASE..BASE+3 (rows = this wave's block, 4 column blocks)
+template <int BASE>
+DEV void dw_gemm_s_agpr(const char* TA, const char* TB, float& dbacc, int wave, int lane) {
+  int a0[2];
+  ts_lane_offsets(lane, a0);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const bf16x8 fa = ts_read(TA, a0, wave, ks);
+    const bf16x8 f0 = ts_read(TB, a0, 0, ks), f1 = ts_read(TB, a0, 1, ks);
+    const bf16x8 f2 = ts_read(TB, a0, 2, ks), f3 = ts_read(TB, a0, 3, ks);
+    mfma_bf16_agpr_tile<BASE + 0, false>(fa, f0);
+    mfma_bf16_agpr_tile<BASE + 1, false>(fa, f1);
+    mfma_bf16_agpr_tile<BASE + 2, false>(fa, f2);
+    if (ks == 7) mfma_bf16_agpr_tile<BASE + 3, true>(fa, f3);
+    else mfma_bf16_agpr_tile<BASE + 3, false>(fa, f3);
+    dbacc += frag_sum<PolBF16>(fa);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ==========================================================================================
 // bf16 TRAINING kernel with register-persistent weight-gradient accumulators (H = 128, L <= 5)
 // ==========================================================================================
@@ -834,7 +901,7 @@ DEV float phase_hi(unsigned w) { return __uint_as_float(((w >> 9) & 0x007fff80u)
 //     CU's register file) stay in registers across the workgroup's whole tile loop and are written
 //     ONCE per launch.  hipcc allocates every MFMA accumulator of a kernel in AGPRs (256 = sixteen
 //     32x32 tiles), so the tiles are pinned by hand: layers 2..5 in AGPRs, layer 1 in VGPRs
-//     (mfma_bf16_pin_a / _v).  The generic kernel's per-tile "+=" flush of those partials was 65 % of
+//     (mfma_bf16_agpr_tile).  The generic kernel's per-tile "+=" flush of those partials was 65 % of
 //     its run time (profiles/r01_b_ablation.md);
 //   * one workgroup (4 waves, one per SIMD, up to 512 registers each) per CU;
 //   * activations / gradients travel between layers as packed bf16 MFMA operands;
@@ -845,6 +912,7 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
   using Pol = PolBF16;
   using G = Geo<Pol, H>;
   using GP = GeoP<H>;
+  static_assert(H == 128, "sample-major transposition image is laid out for H = 128");
   constexpr int NRB = G::NRB, NKS = G::NKS;
   constexpr int MYB_H = (NRB * NRB + 3) / 4;
   constexpr int PMAX = 5;
@@ -866,10 +934,11 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
   const int L = a.L;
   const int nstep = 2 * L + 2;  // weight images consumed per tile
 
-  f32x16 pacc[PMAX][MYB_H];
+  static_assert(MYB_H == 4, "sixteen AGPR tiles = 4 layers x 4 column blocks");
+  agpr_zero_seq(std::make_integer_sequence<int, 256>{});  // dW_2..dW_5 accumulators: a[0:255]
   float pdb[PMAX];
 #pragma unroll
-  for (int l = 0; l < PMAX; ++l) { acc_zero<MYB_H>(pacc[l]); pdb[l] = 0.f; }
+  for (int l = 0; l < PMAX; ++l) pdb[l] = 0.f;
   bool first = true;
 
   int lane16 = lane * 16, tid16 = tid * 16;  // re-made opaque at the top of every tile iteration
@@ -905,10 +974,12 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) xl[k] = (__bf16)(x[k] - (float)xh[k]);
 
-    bf16x8 hb[NKS];  // current activations as MFMA B operands
+    bf16x8 hb[NKS];       // current activations as MFMA B operands
+    u32x4 qst[NRB * 2];   // phases of the layer just computed; stored at the START of the next step so
+                          // that the barrier after it never waits for these stores (vmcnt counts stores)
 
-    // activation of one finished row block: stash the phase, keep bf16 sin
-    auto activate = [&](const f32x16& acc, int rb, float sc, bf16x8 (&dst)[NKS], char* sl) {
+    // activation of one finished row block: keep the phase (for the stash) and the bf16 sin
+    auto activate = [&](const f32x16& acc, int rb, float sc, bf16x8 (&dst)[NKS]) {
       unsigned q[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -917,12 +988,14 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
         dst[2 * rb + (r >> 3)][r & 7] = (__bf16)__builtin_amdgcn_sinf(th);
       }
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        u32x4 w;
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int d = 0; d < 4; ++d) w[d] = q[8 * c + 2 * d] | (q[8 * c + 2 * d + 1] << 16);
-        *(u32x4*)(sl + (2 * rb + c) * 4096 + tid16) = w;
-      }
+        for (int d = 0; d < 4; ++d) qst[2 * rb + c][d] = q[8 * c + 2 * d] | (q[8 * c + 2 * d + 1] << 16);
+    };
+    auto store_stash = [&](int layer) {
+      char* sl = stash + (size_t)layer * G::STASH_LAYER_BYTES;
+#pragma unroll
+      for (int c = 0; c < NRB * 2; ++c) *(u32x4*)(sl + c * 4096 + tid16) = qst[c];
     };
 
     // ---- layer 0 (per-image affine map, split-bf16 operands: see k_reni_main)
@@ -945,8 +1018,8 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = PolBF16::mfma(aop, bop, acc);
-        activate(acc, rbo, sc_first, hb, stash);
+        mfma_bf16_pin_v<true>(acc, aop, bop);
+        activate(acc, rbo, sc_first, hb);
       }
     }
 
@@ -956,10 +1029,10 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
     for (int l = 1; l <= L; ++l) {
       __syncthreads();  // image of this step landed (vmcnt(0) before the barrier); the other buffer is free
       TRACE(10 + l);
+      store_stash(l - 1);
       issue_dma(l);
       const char* wb = smem + ((l - 1) & 1) * GP::WBSZ;
       const float* bias = (const float*)(wb + G::IMG_HID);
-      char* sl = stash + (size_t)l * G::STASH_LAYER_BYTES;
       bf16x8 hn[NKS];
 #pragma unroll
       for (int rbo = 0; rbo < NRB; ++rbo) {
@@ -967,7 +1040,7 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = bias[32 * rbo + rowmap(r, hi)];
         acc = gemm_rb<NKS>(wb, rbo, hb, acc, lane);
-        activate(acc, rbo, sc_hidden, hn, sl);
+        activate(acc, rbo, sc_hidden, hn);
       }
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) hb[ks] = hn[ks];
@@ -979,6 +1052,7 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
     {
       __syncthreads();
       TRACE(4);
+      store_stash(L);
       issue_dma(L + 1);
       const char* wb = smem + (L & 1) * GP::WBSZ;
       const float* bias = (const float*)(wb + G::IMG_HF);
@@ -1050,14 +1124,18 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
       for (int r = 0; r < 16; ++r) ghb[2 * rbi + (r >> 3)][r & 7] = (__bf16)acc[r];
     };
     // g_a = g_h * omega * cos(phase) for one layer's stash
-    auto make_g = [&](const char* sl, float omega) {
+    auto load_phases = [&](const char* sl, u32x4 (&w)[NRB * 2]) {  // all loads in flight together
+#pragma unroll
+      for (int c = 0; c < NRB * 2; ++c) w[c] = *(const u32x4*)(sl + c * 4096 + tid16);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto make_g = [&](const u32x4 (&w)[NRB * 2], float omega) {
 #pragma unroll
       for (int c = 0; c < NRB * 2; ++c) {
-        const u32x4 w = *(const u32x4*)(sl + c * 4096 + tid16);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-          gb[c][2 * d] = (__bf16)((float)ghb[c][2 * d] * omega * __builtin_amdgcn_cosf(phase_lo(w[d])));
-          gb[c][2 * d + 1] = (__bf16)((float)ghb[c][2 * d + 1] * omega * __builtin_amdgcn_cosf(phase_hi(w[d])));
+          gb[c][2 * d] = (__bf16)((float)ghb[c][2 * d] * omega * __builtin_amdgcn_cosf(phase_lo(w[c][d])));
+          gb[c][2 * d + 1] = (__bf16)((float)ghb[c][2 * d + 1] * omega * __builtin_amdgcn_cosf(phase_hi(w[c][d])));
         }
       }
     };
@@ -1067,8 +1145,8 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { gyb[0][e] = (__bf16)((e < 3) ? gy[e] : 0.f); gyb[1][e] = (__bf16)0.f; }
       __syncthreads();  // B1: TA/TB free (previous tile's layer-0 phase done)
-      t_write_b<H, NRB>(TA, hb, wave, hi, j);
-      t_write_b<H, 1>(TB, gyb, wave, hi, j);
+      ts_write<NRB>(TA, hb, wave * 32 + j, hi);
+      ts_write<1>(TB, gyb, wave * 32 + j, hi);
       __syncthreads();  // B2
       TRACE(7);
       issue_dma(L + 2 < nstep ? L + 2 : 0);
@@ -1076,7 +1154,7 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
         f32x16 ah[1];
         acc_zero<1>(ah);
         float dbh = 0.f;
-        dw_gemm<Pol, H, NRB, 1, DW_HEAD, 1>(TA, TB, ah, dbh, wave, lane);
+        dw_gemm_s<1, DW_HEAD, 2>(TA, TB, ah, dbh, wave, lane);
         dw_flush<Pol, H, NRB, 1, DW_HEAD, 1>(ah, dbh, dwp + a.p_off_w[L + 1], dwp + a.p_off_b[L + 1], H, first, wave, lane);
       }
       const char* wb = smem + ((L + 1) & 1) * GP::WBSZ;
@@ -1089,7 +1167,10 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
     for (int l = L; l >= 1; --l) {
       const int k = 2 * L + 2 - l;
       TRACE(20 + l);
-      make_g(stash + (size_t)l * G::STASH_LAYER_BYTES, a.w_hidden);
+      u32x4 wph[NRB * 2];
+      load_phases(stash + (size_t)l * G::STASH_LAYER_BYTES, wph);
+      make_g(wph, a.w_hidden);
+      load_phases(stash + (size_t)(l - 1) * G::STASH_LAYER_BYTES, wph);  // for h_{l-1}; lands while we sync
       if (l == 1) {  // the sixteen AGPR tiles hold dW_2..dW_5; dW_1 = sum g_1 h_0^T is finished by k_reni_dw1
         char* gp = a.g1 + (size_t)tile * (NKS * 4096);
 #pragma unroll
@@ -1098,21 +1179,18 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
       TRACE(30 + l);
       __syncthreads();  // B1: every wave finished the previous step's LDS reads
       TRACE(40 + l);
-      t_write_b<H, NRB>(TA, gb, wave, hi, j);
+      ts_write<NRB>(TA, gb, wave * 32 + j, hi);
       TRACE(80 + l);
-      {  // h_{l-1} = sin(phase_{l-1}) straight into the transposed image (needed as dW_l's column operand)
-        const char* sp = stash + (size_t)(l - 1) * G::STASH_LAYER_BYTES;
+      // h_{l-1} = sin(phase_{l-1}) straight into the transposed image (dW_l's column operand)
 #pragma unroll
-        for (int c = 0; c < NRB * 2; ++c) {
-          const u32x4 w = *(const u32x4*)(sp + c * 4096 + tid16);
+      for (int c = 0; c < NRB * 2; ++c) {
+        bf16x8 hv;
 #pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            const int r = (c & 1) * 8 + 2 * d;
-            const int f0 = 32 * (c >> 1) + rowmap(r, hi), f1 = 32 * (c >> 1) + rowmap(r + 1, hi);
-            *(__bf16*)(TB + f0 * G::T_ROWB + (wave * 32 + j) * 2) = (__bf16)__builtin_amdgcn_sinf(phase_lo(w[d]));
-            *(__bf16*)(TB + f1 * G::T_ROWB + (wave * 32 + j) * 2) = (__bf16)__builtin_amdgcn_sinf(phase_hi(w[d]));
-          }
+        for (int d = 0; d < 4; ++d) {
+          hv[2 * d] = (__bf16)__builtin_amdgcn_sinf(phase_lo(wph[c][d]));
+          hv[2 * d + 1] = (__bf16)__builtin_amdgcn_sinf(phase_hi(wph[c][d]));
         }
+        ts_write_chunk(TB, hv, c, wave * 32 + j, hi);
       }
       TRACE(50 + l);
       __syncthreads();  // B2
@@ -1120,10 +1198,10 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
       if (k + 1 < nstep) issue_dma(k + 1);
       else if (tile + (int)gridDim.x < a.n_tiles) issue_dma(0);
       switch (l) {  // one static register set per layer
-        case 5: dw_gemm<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, pacc[4], pdb[4], wave, lane); break;
-        case 4: dw_gemm<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, pacc[3], pdb[3], wave, lane); break;
-        case 3: dw_gemm<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, pacc[2], pdb[2], wave, lane); break;
-        case 2: dw_gemm<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H, 1>(TA, TB, pacc[1], pdb[1], wave, lane); break;
+        case 5: dw_gemm_s_agpr<12>(TA, TB, pdb[4], wave, lane); break;
+        case 4: dw_gemm_s_agpr<8>(TA, TB, pdb[3], wave, lane); break;
+        case 3: dw_gemm_s_agpr<4>(TA, TB, pdb[2], wave, lane); break;
+        case 2: dw_gemm_s_agpr<0>(TA, TB, pdb[1], wave, lane); break;
         default: break;  // layer 1: handled by k_reni_dw1 from the g_1 stream stored below
       }
       TRACE(70 + l);
@@ -1134,7 +1212,9 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
     TRACE(8);
     // ---- layer 0: dA (per tile) = g_0 (x_hi | x_lo)^T
     {
-      make_g(stash, a.w_first);
+      u32x4 wph[NRB * 2];
+      load_phases(stash, wph);
+      make_g(wph, a.w_first);
       bf16x8 xcb[2];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { xcb[0][e] = (__bf16)0.f; xcb[1][e] = (__bf16)0.f; }
@@ -1145,23 +1225,32 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
         xcb[0][0] = (__bf16)1.f;
       }
       __syncthreads();
-      t_write_b<H, NRB>(TA, gb, wave, hi, j);
-      t_write_b<H, 1>(TB, xcb, wave, hi, j);
+      ts_write<NRB>(TA, gb, wave * 32 + j, hi);
+      ts_write<1>(TB, xcb, wave * 32 + j, hi);
       __syncthreads();
       f32x16 accA[1];
       acc_zero<1>(accA);
       float dummy = 0.f;
-      dw_gemm<Pol, H, NRB, 1, DW_L0, 1>(TA, TB, accA, dummy, wave, lane);
+      dw_gemm_s<1, DW_L0, 2>(TA, TB, accA, dummy, wave, lane);
       dw_flush<Pol, H, NRB, 1, DW_L0, 1>(accA, 0.f, a.dA_part + (size_t)tile * H * 16, nullptr, 16, true, wave, lane);
     }
     TRACE(9);
     first = false;
   }
   // ---- the only write of the hidden-layer weight-gradient partials: once per workgroup per launch
-#pragma unroll
-  for (int l = 2; l <= PMAX; ++l)
-    if (l <= L)
-      dw_flush<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H>(pacc[l - 1], pdb[l - 1], dwp + a.p_off_w[l], dwp + a.p_off_b[l], H, true, wave, lane);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  auto flush_layer = [&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    if (l <= L) {
+      f32x16 t[MYB_H] = {agpr_read_tile<4 * (l - 2) + 0>(), agpr_read_tile<4 * (l - 2) + 1>(),
+                         agpr_read_tile<4 * (l - 2) + 2>(), agpr_read_tile<4 * (l - 2) + 3>()};
+      dw_flush<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H>(t, pdb[l - 1], dwp + a.p_off_w[l], dwp + a.p_off_b[l], H, true, wave, lane);
+    }
+  };
+  flush_layer(std::integral_constant<int, 2>{});
+  flush_layer(std::integral_constant<int, 3>{});
+  flush_layer(std::integral_constant<int, 4>{});
+  flush_layer(std::integral_constant<int, 5>{});
 }
 template __global__ void k_reni_train_bf16<128>(const MainArgs);
 
@@ -1176,7 +1265,7 @@ __global__ void __launch_bounds__(256, 2) k_reni_dw1(const MainArgs a) {
   constexpr int MYB_H = (NRB * NRB + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const TA = smem;
-  char* const TB = smem + G::T_BYTES_AL;
+  char* const TB = smem + TS_BYTES;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, hi = lane >> 5, j = lane & 31;
@@ -1237,10 +1326,10 @@ __global__ void __launch_bounds__(256, 2) k_reni_dw1(const MainArgs a) {
       }
     }
     __syncthreads();
-    t_write_b<H, NRB>(TA, gb, wave, hi, j);
-    t_write_b<H, NRB>(TB, hb, wave, hi, j);
+    ts_write<NRB>(TA, gb, wave * 32 + j, hi);
+    ts_write<NRB>(TB, hb, wave * 32 + j, hi);
     __syncthreads();
-    dw_gemm<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H>(TA, TB, acc, db, wave, lane);
+    dw_gemm_s<NRB, DW_HIDDEN, 0>(TA, TB, acc, db, wave, lane);
   }
   float* const dwp = a.dwp + (size_t)blockIdx.x * a.dwp_per_wg;
   dw_flush<Pol, H, NRB, NRB, DW_HIDDEN, MYB_H>(acc, db, dwp + a.p_off_w[1], dwp + a.p_off_b[1], H, true, wave, lane);
