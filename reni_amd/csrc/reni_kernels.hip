@@ -359,9 +359,9 @@ DEV f32x16 agpr_read_tile() { return agpr_read_tile_seq<T>(std::make_integer_seq
 template <bool LAST>
 DEV void mfma_bf16_pin_v(f32x16& acc, bf16x8 a, bf16x8 b) {
   if constexpr (LAST)
-    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(acc) : "v"(a), "v"(b));
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(acc) : "v"(a), "v"(b));
   else
-    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
 // K = samples GEMM from the transposed LDS images: acc[m] += rows-block x cols-block over one round
@@ -746,7 +746,7 @@ struct GeoP {
   using G = Geo<PolBF16, H>;
   static constexpr int WBSZ = (G::IMG_HID + G::BIAS_HID + 1023) & ~1023;  // DMA moves 1 KB pieces
   static constexpr int TSZ = 128 * 256;  // sample-major image, see ts_write / ts_read
-  static constexpr int LDS_BYTES = 2 * WBSZ + 2 * TSZ;
+  static constexpr int LDS_BYTES = 2 * WBSZ + 2 * TSZ + 2048;  // + head dW accumulators
 };
 
 // async global -> LDS copy of `bytes` (rounded up to 1 KB; the image regions are padded) split over 4 waves
@@ -777,6 +777,20 @@ DEV f32x16 gemm_rb(const char* wb, int rbo, const bf16x8 (&bop)[NKS], f32x16 acc
     else mfma_bf16_pin_v<false>(acc, a, bop[ks]);
   }
   return acc;
+}
+
+// two row blocks at once: their MFMA chains are independent, so alternating them keeps the matrix pipe
+// busy instead of waiting out each dependent-accumulator latency
+template <int NKS>
+DEV void gemm_rb2(const char* wb, int rbo0, const bf16x8 (&bop)[NKS], f32x16& acc0, f32x16& acc1, int lane) {
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const bf16x8 a0 = *(const bf16x8*)(wb + ((rbo0 * NKS + ks) * 64 + lane) * 16);
+    const bf16x8 a1 = *(const bf16x8*)(wb + (((rbo0 + 1) * NKS + ks) * 64 + lane) * 16);
+    mfma_bf16_pin_v<false>(acc0, a0, bop[ks]);
+    if (ks == NKS - 1) mfma_bf16_pin_v<true>(acc1, a1, bop[ks]);
+    else mfma_bf16_pin_v<false>(acc1, a1, bop[ks]);
+  }
 }
 
 template <int H, int NB>
@@ -919,6 +933,7 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const TA = smem + 2 * GP::WBSZ;
   char* const TB = TA + GP::TSZ;
+  float* const hdw = (float*)(TB + GP::TSZ);  // [3][H] dW_out + [3] db_out accumulated over the tile loop
 
 #ifdef RENI_TRACE
   int trace_n = 0;
@@ -939,7 +954,7 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
   float pdb[PMAX];
 #pragma unroll
   for (int l = 0; l < PMAX; ++l) pdb[l] = 0.f;
-  bool first = true;
+  for (int i = tid; i < 3 * H + 4; i += 256) hdw[i] = 0.f;
 
   int lane16 = lane * 16, tid16 = tid * 16;  // re-made opaque at the top of every tile iteration
   // image of step k of a tile: k < L hidden fwd (layer k+1), k == L head fwd, k == L+1 head bwd,
@@ -968,6 +983,20 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
       x[3] = sqrtf(x[0] * x[0] + x[2] * x[2]);
       x[4] = 1.f;
     }
+    const bool owner = valid && (hi == 0);
+    float tgt[3] = {0.f, 0.f, 0.f}, swt[3] = {0.f, 0.f, 0.f};  // issued now, consumed after the forward pass
+    if (owner) {
+      if (a.loss_kind == 2) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tgt[c] = a.dout[((size_t)b * a.P + p) * 3 + c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          tgt[c] = a.target[(size_t)b * a.ts0 + (size_t)p * a.ts1 + (size_t)c * a.ts2];
+          swt[c] = a.weight[(size_t)b * a.ws0 + (size_t)p * a.ws1 + (size_t)c * a.ws2];
+        }
+      }
+    }
     __bf16 xh[5], xl[4];
 #pragma unroll
     for (int k = 0; k < 5; ++k) xh[k] = (__bf16)x[k];
@@ -980,17 +1009,17 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
 
     // activation of one finished row block: keep the phase (for the stash) and the bf16 sin
     auto activate = [&](const f32x16& acc, int rb, float sc, bf16x8 (&dst)[NKS]) {
-      unsigned q[16];
+      float th[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float th = __builtin_amdgcn_fractf(acc[r] * sc);
-        q[r] = ((unsigned)(th * 65536.f + 0.5f)) & 0xffffu;
-        dst[2 * rb + (r >> 3)][r & 7] = (__bf16)__builtin_amdgcn_sinf(th);
+        th[r] = __builtin_amdgcn_fractf(acc[r] * sc);
+        dst[2 * rb + (r >> 3)][r & 7] = (__bf16)__builtin_amdgcn_sinf(th[r]);
       }
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int d = 0; d < 4; ++d) qst[2 * rb + c][d] = q[8 * c + 2 * d] | (q[8 * c + 2 * d + 1] << 16);
+        for (int d = 0; d < 4; ++d)  // two phases -> two unorm16 in ONE instruction (v_cvt_pknorm_u16_f32)
+          qst[2 * rb + c][d] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(th[8 * c + 2 * d], th[8 * c + 2 * d + 1]));
     };
     auto store_stash = [&](int layer) {
       char* sl = stash + (size_t)layer * G::STASH_LAYER_BYTES;
@@ -1035,12 +1064,16 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
       const float* bias = (const float*)(wb + G::IMG_HID);
       bf16x8 hn[NKS];
 #pragma unroll
-      for (int rbo = 0; rbo < NRB; ++rbo) {
-        f32x16 acc;
+      for (int rbo = 0; rbo < NRB; rbo += 2) {
+        f32x16 acc0, acc1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = bias[32 * rbo + rowmap(r, hi)];
-        acc = gemm_rb<NKS>(wb, rbo, hb, acc, lane);
-        activate(acc, rbo, sc_hidden, hn);
+        for (int r = 0; r < 16; ++r) {
+          acc0[r] = bias[32 * rbo + rowmap(r, hi)];
+          acc1[r] = bias[32 * rbo + 32 + rowmap(r, hi)];
+        }
+        gemm_rb2<NKS>(wb, rbo, hb, acc0, acc1, lane);
+        activate(acc0, rbo, sc_hidden, hn);
+        activate(acc1, rbo + 1, sc_hidden, hn);
       }
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) hb[ks] = hn[ks];
@@ -1067,7 +1100,6 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
         outv[c] = (a.act == 1) ? tanhf(yv) : (a.act == 2) ? expf(yv) : yv;
       }
     }
-    const bool owner = valid && (hi == 0);
     if (a.out != nullptr && owner) {
       float* op = a.out + ((size_t)b * a.P + p) * 3;
       op[0] = outv[0]; op[1] = outv[1]; op[2] = outv[2];
@@ -1080,14 +1112,13 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
       float e = 0.f;
       if (a.loss_kind == 2) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) gy[c] = owner ? a.dout[((size_t)b * a.P + p) * 3 + c] : 0.f;
+        for (int c = 0; c < 3; ++c) gy[c] = tgt[c];
       } else {
         const float inv3p = 1.0f / (3.0f * (float)a.P);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           if (owner) {
-            const float t = a.target[(size_t)b * a.ts0 + (size_t)p * a.ts1 + (size_t)c * a.ts2];
-            const float sw = a.weight[(size_t)b * a.ws0 + (size_t)p * a.ws1 + (size_t)c * a.ws2];
+            const float t = tgt[c], sw = swt[c];
             const float d = outv[c] - t;
             e += sw * d * d;
             gy[c] = 2.f * sw * d * inv3p;
@@ -1114,14 +1145,17 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
     bf16x8 gb[NKS];   // gradient w.r.t. the current layer's pre-activation (g_a), packed
     bf16x8 ghb[NKS];  // dX result of the current step (g_h), packed as soon as a row block is done
     // one row block of a dX GEMM -> packed bf16 (only ONE fp32 accumulator tile is ever live)
-    auto dx_rowblock = [&](const char* wb, int rbi, auto& bop, auto nks_tag) {
+    auto dx_rowblock = [&](const char* wb, int rbi, auto& bop, auto nks_tag) {  // row blocks rbi, rbi+1
       constexpr int NK = decltype(nks_tag)::value;
-      f32x16 acc;
+      f32x16 acc0, acc1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      acc = gemm_rb<NK>(wb, rbi, bop, acc, lane);
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      gemm_rb2<NK>(wb, rbi, bop, acc0, acc1, lane);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ghb[2 * rbi + (r >> 3)][r & 7] = (__bf16)acc[r];
+      for (int r = 0; r < 16; ++r) {
+        ghb[2 * rbi + (r >> 3)][r & 7] = (__bf16)acc0[r];
+        ghb[2 * rbi + 2 + (r >> 3)][r & 7] = (__bf16)acc1[r];
+      }
     };
     // g_a = g_h * omega * cos(phase) for one layer's stash
     auto load_phases = [&](const char* sl, u32x4 (&w)[NRB * 2]) {  // all loads in flight together
@@ -1155,12 +1189,17 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
         acc_zero<1>(ah);
         float dbh = 0.f;
         dw_gemm_s<1, DW_HEAD, 2>(TA, TB, ah, dbh, wave, lane);
-        dw_flush<Pol, H, NRB, 1, DW_HEAD, 1>(ah, dbh, dwp + a.p_off_w[L + 1], dwp + a.p_off_b[L + 1], H, first, wave, lane);
+        if (j < 3) {  // element (c = j, feature) is owned by exactly one lane of one wave: plain LDS +=
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hdw[j * H + 32 * wave + rowmap(r, hi)] += ah[0][r];
+        }
+        dbh += __shfl_xor(dbh, 32, 64);
+        if (wave == 0 && hi == 0 && j < 3) hdw[3 * H + j] += dbh;
       }
       const char* wb = smem + ((L + 1) & 1) * GP::WBSZ;
       const bf16x8 g1[1] = {gyb[0]};
 #pragma unroll
-      for (int rbi = 0; rbi < NRB; ++rbi) dx_rowblock(wb, rbi, g1, std::integral_constant<int, 1>{});
+      for (int rbi = 0; rbi < NRB; rbi += 2) dx_rowblock(wb, rbi, g1, std::integral_constant<int, 1>{});
     }
     // ---- hidden layers l = L..1 (step k = 2L+2-l)
 #pragma unroll 1
@@ -1207,7 +1246,7 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
       TRACE(70 + l);
       const char* wb = smem + (k & 1) * GP::WBSZ;
 #pragma unroll
-      for (int rbi = 0; rbi < NRB; ++rbi) dx_rowblock(wb, rbi, gb, std::integral_constant<int, NKS>{});
+      for (int rbi = 0; rbi < NRB; rbi += 2) dx_rowblock(wb, rbi, gb, std::integral_constant<int, NKS>{});
     }
     TRACE(8);
     // ---- layer 0: dA (per tile) = g_0 (x_hi | x_lo)^T
@@ -1235,9 +1274,11 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
       dw_flush<Pol, H, NRB, 1, DW_L0, 1>(accA, 0.f, a.dA_part + (size_t)tile * H * 16, nullptr, 16, true, wave, lane);
     }
     TRACE(9);
-    first = false;
   }
   // ---- the only write of the hidden-layer weight-gradient partials: once per workgroup per launch
+  __syncthreads();
+  for (int i = tid; i < 3 * H; i += 256) dwp[a.p_off_w[L + 1] + i] = hdw[i];
+  if (tid < 3) dwp[a.p_off_b[L + 1] + tid] = hdw[3 * H + tid];
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   auto flush_layer = [&](auto lc) {
     constexpr int l = decltype(lc)::value;
@@ -1320,7 +1361,7 @@ __global__ void __launch_bounds__(256, 2) k_reni_dw1(const MainArgs a) {
         for (int r = 0; r < 16; ++r) {
           // same phase quantisation as the training kernel's stash, so h_0 is bit-identical to what it used
           const float th = __builtin_amdgcn_fractf(a0[r] * sc_first);
-          const unsigned q = ((unsigned)(th * 65536.f + 0.5f)) & 0xffffu;
+          const unsigned q = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(th, 0.f)) & 0xffffu;
           hb[2 * rbo + (r >> 3)][r & 7] = (__bf16)__builtin_amdgcn_sinf(__uint_as_float((q << 7) | 0x3f800000u));
         }
       }
