@@ -892,11 +892,16 @@ template <int BASE>
 DEV void dw_gemm_s_agpr(const char* TA, const char* TB, float& dbacc, int wave, int lane) {
   int a0[2];
   ts_lane_offsets(lane, a0);
+  bf16x8 fa = ts_read(TA, a0, wave, 0);
+  bf16x8 f0 = ts_read(TB, a0, 0, 0), f1 = ts_read(TB, a0, 1, 0), f2 = ts_read(TB, a0, 2, 0), f3 = ts_read(TB, a0, 3, 0);
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
-    const bf16x8 fa = ts_read(TA, a0, wave, ks);
-    const bf16x8 f0 = ts_read(TB, a0, 0, ks), f1 = ts_read(TB, a0, 1, ks);
-    const bf16x8 f2 = ts_read(TB, a0, 2, ks), f3 = ts_read(TB, a0, 3, ks);
+    bf16x8 na = fa, n0 = f0, n1 = f1, n2 = f2, n3 = f3;
+    if (ks < 7) {  // next k-step's fragments are in flight while this k-step's MFMAs run
+      na = ts_read(TA, a0, wave, ks + 1);
+      n0 = ts_read(TB, a0, 0, ks + 1); n1 = ts_read(TB, a0, 1, ks + 1);
+      n2 = ts_read(TB, a0, 2, ks + 1); n3 = ts_read(TB, a0, 3, ks + 1);
+    }
     mfma_bf16_agpr_tile<BASE + 0, false>(fa, f0);
     mfma_bf16_agpr_tile<BASE + 1, false>(fa, f1);
     mfma_bf16_agpr_tile<BASE + 2, false>(fa, f2);
@@ -904,6 +909,7 @@ DEV void dw_gemm_s_agpr(const char* TA, const char* TB, float& dbacc, int wave, 
     else mfma_bf16_agpr_tile<BASE + 3, false>(fa, f3);
     dbacc += frag_sum<PolBF16>(fa);
     __builtin_amdgcn_sched_barrier(0);
+    fa = na; f0 = n0; f1 = n1; f2 = n2; f3 = n3;
   }
 }
 
@@ -1299,7 +1305,7 @@ template __global__ void k_reni_train_bf16<128>(const MainArgs);
 // D layout, written by k_reni_train_bf16) with h_0 = sin(w0 (A_b x)) recomputed from the directions.
 // Persistent workgroups; the 128 x 128 accumulator stays in registers over all of a workgroup's tiles.
 template <int H>
-__global__ void __launch_bounds__(256, 2) k_reni_dw1(const MainArgs a) {
+__global__ void __launch_bounds__(256, 1) k_reni_dw1(const MainArgs a) {
   using Pol = PolBF16;
   using G = Geo<Pol, H>;
   constexpr int NRB = G::NRB, NKS = G::NKS;
@@ -1314,39 +1320,56 @@ __global__ void __launch_bounds__(256, 2) k_reni_dw1(const MainArgs a) {
   acc_zero<MYB_H>(acc);
   float db = 0.f;
   const float sc_first = a.w_first * 0.15915494309189535f;
-#pragma unroll 1
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+
+  // inputs of a tile: the g_1 fragments, this lane's direction and its four rows of A_b.  They are
+  // fetched one tile ahead so their HBM latency hides behind the previous tile's work.
+  bf16x8 gbN[NKS];
+  float dN[3];
+  f32x4 aloN[NRB];
+  float a4N[NRB];
+  auto fetch = [&](int tile) {
     const int b = tile / a.tiles_per_image;
     const int p = (tile - b * a.tiles_per_image) * 128 + wave * 32 + j;
-    const bool valid = p < a.P;
-    float x[5];
-    {
-      const float* dp = a.D + (size_t)b * a.d_bstride + (size_t)(valid ? p : 0) * 3;
-      x[0] = dp[0]; x[1] = dp[1]; x[2] = dp[2];
-      x[3] = sqrtf(x[0] * x[0] + x[2] * x[2]);
-      x[4] = 1.f;
+    const float* dp = a.D + (size_t)b * a.d_bstride + (size_t)(p < a.P ? p : 0) * 3;
+    dN[0] = dp[0]; dN[1] = dp[1]; dN[2] = dp[2];
+    const char* gp = a.g1 + (size_t)tile * (NKS * 4096);
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) gbN[c] = *(const bf16x8*)(gp + c * 4096 + tid * 16);
+    const float* Ab = a.Apre + (size_t)b * H * 8;
+#pragma unroll
+    for (int rbo = 0; rbo < NRB; ++rbo) {
+      aloN[rbo] = *(const f32x4*)(Ab + (32 * rbo + j) * 8);
+      a4N[rbo] = Ab[(32 * rbo + j) * 8 + 4];
     }
+  };
+  if ((int)blockIdx.x < a.n_tiles) fetch(blockIdx.x);
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    bf16x8 gb[NKS];
+    float x[5];
+    f32x4 alo[NRB];
+    float a4[NRB];
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) gb[c] = gbN[c];
+    x[0] = dN[0]; x[1] = dN[1]; x[2] = dN[2];
+#pragma unroll
+    for (int rbo = 0; rbo < NRB; ++rbo) { alo[rbo] = aloN[rbo]; a4[rbo] = a4N[rbo]; }
+    if (tile + (int)gridDim.x < a.n_tiles) fetch(tile + gridDim.x);
+    x[3] = sqrtf(x[0] * x[0] + x[2] * x[2]);
+    x[4] = 1.f;
     __bf16 xh[5], xl[4];
 #pragma unroll
     for (int k = 0; k < 5; ++k) xh[k] = (__bf16)x[k];
 #pragma unroll
     for (int k = 0; k < 4; ++k) xl[k] = (__bf16)(x[k] - (float)xh[k]);
-    bf16x8 hb[NKS], gb[NKS];
+    bf16x8 hb[NKS];
     {
-      const char* gp = a.g1 + (size_t)tile * (NKS * 4096);
-#pragma unroll
-      for (int c = 0; c < NKS; ++c) gb[c] = *(const bf16x8*)(gp + c * 4096 + tid * 16);
-    }
-    {
-      const float* Ab = a.Apre + (size_t)b * H * 8;
       bf16x8 bop;
       if (hi == 0) { bop[0] = xh[0]; bop[1] = xh[1]; bop[2] = xh[2]; bop[3] = xh[3]; bop[4] = xh[4]; bop[5] = xh[0]; bop[6] = xh[1]; bop[7] = xh[2]; }
       else { bop[0] = xh[3]; bop[1] = xh[4]; bop[2] = xl[0]; bop[3] = xl[1]; bop[4] = xl[2]; bop[5] = xl[3]; bop[6] = (__bf16)0.f; bop[7] = (__bf16)0.f; }
 #pragma unroll
       for (int rbo = 0; rbo < NRB; ++rbo) {
-        const f32x4 lo4 = *(const f32x4*)(Ab + (32 * rbo + j) * 8);
-        const float a4 = Ab[(32 * rbo + j) * 8 + 4];
-        const float A5[5] = {lo4[0], lo4[1], lo4[2], lo4[3], a4};
+        const float A5[5] = {alo[rbo][0], alo[rbo][1], alo[rbo][2], alo[rbo][3], a4[rbo]};
         __bf16 Ah[5], Al[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) { Ah[k] = (__bf16)A5[k]; Al[k] = (__bf16)(A5[k] - (float)Ah[k]); }
