@@ -783,13 +783,20 @@ DEV f32x16 gemm_rb(const char* wb, int rbo, const bf16x8 (&bop)[NKS], f32x16 acc
 // busy instead of waiting out each dependent-accumulator latency
 template <int NKS>
 DEV void gemm_rb2(const char* wb, int rbo0, const bf16x8 (&bop)[NKS], f32x16& acc0, f32x16& acc1, int lane) {
+  // A fragments are fetched two k-steps ahead of the MFMAs that use them (LDS latency ~ 2 MFMA pairs)
+  auto fa = [&](int r, int ks) { return *(const bf16x8*)(wb + (((rbo0 + r) * NKS + ks) * 64 + lane) * 16); };
+  constexpr int D = NKS >= 2 ? 2 : 1;
+  bf16x8 q0[D], q1[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) { q0[d] = fa(0, d); q1[d] = fa(1, d); }
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
-    const bf16x8 a0 = *(const bf16x8*)(wb + ((rbo0 * NKS + ks) * 64 + lane) * 16);
-    const bf16x8 a1 = *(const bf16x8*)(wb + (((rbo0 + 1) * NKS + ks) * 64 + lane) * 16);
+    const bf16x8 a0 = q0[ks % D], a1 = q1[ks % D];
+    if (ks + D < NKS) { q0[ks % D] = fa(0, ks + D); q1[ks % D] = fa(1, ks + D); }
     mfma_bf16_pin_v<false>(acc0, a0, bop[ks]);
     if (ks == NKS - 1) mfma_bf16_pin_v<true>(acc1, a1, bop[ks]);
     else mfma_bf16_pin_v<false>(acc1, a1, bop[ks]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -1103,7 +1110,9 @@ __global__ void __launch_bounds__(256, 1) k_reni_train_bf16(const MainArgs a) {
       for (int c = 0; c < 3; ++c) {
         ylin[c] = acc[c];
         const float yv = a.last_linear ? ylin[c] : sin_f32(a.w_hidden * ylin[c]);
-        outv[c] = (a.act == 1) ? tanhf(yv) : (a.act == 2) ? expf(yv) : yv;
+        // tanh(y) = 1 - 2 / (exp(2y) + 1) on the hardware exp2 / rcp (abs error ~1e-6, far inside bf16's)
+        const float e2 = __builtin_amdgcn_exp2f(fminf(yv * 2.885390081777927f, 60.f));
+        outv[c] = (a.act == 1) ? (1.f - 2.f * __builtin_amdgcn_rcpf(e2 + 1.f)) : (a.act == 2) ? expf(yv) : yv;
       }
     }
     if (a.out != nullptr && owner) {

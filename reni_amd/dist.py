@@ -24,7 +24,9 @@ def init_from_env(backend=None):
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("RENI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if os.environ.get("RENI_SHARE_GPU"):  # test hook: several ranks on ONE GPU (gloo only; RCCL needs one GPU per rank)
+        local = 0
     if backend == "nccl":
         torch.cuda.set_device(local)
     if not dist.is_initialized():
