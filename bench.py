@@ -116,6 +116,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:  # create the RCCL communicator outside the timed region even with --warmup 0
+        torch.distributed.all_reduce(torch.zeros(1, device=dev))
     for s in range(args.warmup):
         idx, tgt = batch(s)
         eng.step(idx, tgt, sineweight, directions)
