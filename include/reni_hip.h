@@ -63,7 +63,7 @@ typedef struct reni_plan reni_plan;
 typedef struct reni_desc {
   int32_t equivariance;      /* RENI_EQ_*                                   RENI.py:118-126 */
   int32_t ndims;             /* latent rows ND (Z is [ND,3])                RENI.py:94      */
-  int32_t hidden_features;   /* H: 32, 64 or 128                            RENI.py:96      */
+  int32_t hidden_features;   /* H: 32, 64, 128 or 256                       RENI.py:96      */
   int32_t hidden_layers;     /* L: number of hidden SineLayers after the first (L+1 sine layers) RENI.py:143 */
   int32_t out_features;      /* must be 3                                    RENI.py:98      */
   int32_t last_layer_linear; /* 1: linear head, 0: sine head                RENI.py:153-171 */

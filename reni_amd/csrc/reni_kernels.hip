@@ -51,7 +51,6 @@ struct PolF32 {
   static constexpr int FRAGB = 4;        // bytes per lane of one A/B fragment
   static constexpr int KF = 2;           // features contracted per MFMA (k-step)
   static constexpr int TS = 2;           // samples contracted per MFMA in the dW GEMMs
-  static constexpr int ROUND_WAVES = 1;  // waves whose samples share one dW transposition round
   static constexpr int WPS = 1;          // waves per SIMD to compile for
   static constexpr int HEAD_BWD_KS = 3;  // k-steps that cover the 3 real head outputs
   static constexpr int STASH_CH_PER_RB = 4;  // 16-byte chunks per lane per 32-feature block
@@ -59,19 +58,33 @@ struct PolF32 {
   static DEV f32x16 mfma(Frag a, Frag b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
   }
+  // Wait out the write-back of the last MFMA of a chain before anything else may touch its result.
+  // hipcc's own hazard padding cannot be relied on across branches (ROCm 7.2: it counts a taken
+  // s_cbranch as a wait state and, with an MFMA at the end of a block, was seen to place the pad AFTER
+  // the first read of the result: H = 256 bf16 head dW, nondeterministic rows).  The generic kernels
+  // therefore end every chain with their own pad; tests/test_build_audit.py checks the emitted ISA.
+  static DEV void drain() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 3");  // 16-pass XDL: 18 states (+2)
+    __builtin_amdgcn_sched_barrier(0);
+  }
 };
 struct PolBF16 {
   static constexpr bool BF = true;
   static constexpr int FRAGB = 16;
   static constexpr int KF = 16;
   static constexpr int TS = 16;
-  static constexpr int ROUND_WAVES = 4;
   static constexpr int WPS = 2;
   static constexpr int HEAD_BWD_KS = 1;
   static constexpr int STASH_CH_PER_RB = 2;
   using Frag = bf16x8;
   static DEV f32x16 mfma(Frag a, Frag b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static DEV void drain() {  // see PolF32::drain
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 11");  // 8-pass XDL: 12 states
+    __builtin_amdgcn_sched_barrier(0);
   }
 };
 
@@ -94,14 +107,23 @@ struct Geo {
   static constexpr int IMG_HB = NRB * Pol::HEAD_BWD_KS * 64 * Pol::FRAGB;  // head backward image
   static constexpr int BIAS_HID = H * 4;
   static constexpr int BIAS_HEAD = 32 * 4;
-  static constexpr int ROUND_SAMPLES = 32 * Pol::ROUND_WAVES;
+  // a hidden image is staged into LDS CH_RB row blocks at a time (the whole layer up to H = 128)
+  static constexpr int CH_RB = (H > 128) ? 2 : NRB;
+  static constexpr int NCHUNK = NRB / CH_RB;
+  static constexpr int CHUNK_BYTES = CH_RB * NKS * 64 * Pol::FRAGB;
+  // waves whose samples share one dW transposition round
+  static constexpr int ROUND_WAVES = Pol::BF ? (H > 128 ? 2 : 4) : 1;
+  static constexpr int ROUND_SAMPLES = 32 * ROUND_WAVES;
   // transposition images: bf16 [feature][sample] rows padded by 16 B; fp32 [sample][feature+1]
   static constexpr int T_ROWB = ROUND_SAMPLES * 2 + 16;
   static constexpr int T_BYTES = Pol::BF ? (H * T_ROWB) : (ROUND_SAMPLES * (H + 1) * 4);
   static constexpr int T_BYTES_AL = (T_BYTES + 255) & ~255;
-  static constexpr int WB_RAW = (IMG_HID + BIAS_HID) > T_BYTES_AL ? (IMG_HID + BIAS_HID) : T_BYTES_AL;
+  static constexpr int WB_A = CHUNK_BYTES > T_BYTES_AL ? CHUNK_BYTES : T_BYTES_AL;
+  static constexpr int WB_B = IMG_HF > IMG_HB ? IMG_HF : IMG_HB;
+  static constexpr int WB_RAW = WB_A > WB_B ? WB_A : WB_B;
   static constexpr int WB_BYTES = (WB_RAW + 255) & ~255;
-  static constexpr int LDS_BYTES = WB_BYTES + T_BYTES_AL;
+  static constexpr int BIAS_LDS = (BIAS_HID + 255) & ~255;      // the layer's bias lives after the images
+  static constexpr int LDS_BYTES = WB_BYTES + T_BYTES_AL + BIAS_LDS;
   static constexpr int STASH_CH = NRB * Pol::STASH_CH_PER_RB;   // 16-B chunks per lane per layer
   static constexpr int STASH_LAYER_BYTES = STASH_CH * 256 * 16;
 };
@@ -189,6 +211,7 @@ DEV void gemm_lds(const char* wb, const float (&vin)[NRB_IN][16], f32x16 (&acc)[
         acc[rbo] = PolF32::mfma(a, vin[ks >> 4][ks & 15], acc[rbo]);
       }
   }
+  Pol::drain();
 }
 
 // v: pre-activation a (in)  ->  h = sin(omega a) (out); the sine argument is stashed for backward.
@@ -366,8 +389,9 @@ DEV void mfma_bf16_pin_v(f32x16& acc, bf16x8 a, bf16x8 b) {
 
 // K = samples GEMM from the transposed LDS images: acc[m] += rows-block x cols-block over one round
 // PIN: 0 = compiler-allocated accumulator, 1 = pinned to AGPRs, 2 = pinned to VGPRs (bf16 only)
-template <class Pol, int H, int NBR, int NBC, int KIND, int MYB, int PIN = 0>
-DEV void dw_gemm(const char* TA, const char* TB, f32x16 (&acc)[MYB], float& dbacc, int wave, int lane) {
+template <class Pol, int H, int NBR, int NBC, int KIND, int MYB, int PIN = 0, int M0 = 0>
+DEV void dw_gemm(const char* TA, const char* TB, f32x16 (&acc)[MYB], float& dbacc, int wave, int lane,
+                 float* dbacc2 = nullptr) {  // dbacc2: bias sum of the wave's second row block (NBR == 8)
   using G = Geo<Pol, H>;
   using Frag = typename Pol::Frag;
   constexpr int NBLK = NBR * NBC;
@@ -378,22 +402,30 @@ DEV void dw_gemm(const char* TA, const char* TB, f32x16 (&acc)[MYB], float& dbac
     for (int ks = 0; ks < NKS_T; ++ks) {
 #pragma unroll
       for (int m = 0; m < MYB; ++m) {
-        const int blk = wave + 4 * m;
+        const int blk = wave + 4 * (M0 + m);
         if (blk < NBLK) {
           const int rbo = blk % NBR, cb = blk / NBR;
           Frag fa = t_read<Pol, H, NBR>(TA, rbo, ks, j, hi);
           Frag fb = t_read<Pol, H, NBC>(TB, cb, ks, j, hi);
           acc[m] = Pol::mfma(fa, fb, acc[m]);
-          if (KIND == DW_HIDDEN && m == 0 && cb == 0) dbacc += frag_sum<Pol>(fa);
-          if (KIND == DW_HIDDEN ? false : (KIND == DW_HEAD && m == 0 && blk == 0)) dbacc += frag_sum<Pol>(fb);
+          // bias sums: the owner test is a 0/1 factor, never a branch -- hipcc counts a taken s_cbranch
+          // as one of the 12 wait states between an 8-pass MFMA and the first read of its result, and a
+          // wave that skipped the sum read stale accumulator rows (H = 256 head dW, waves 1..3)
+          if (KIND == DW_HIDDEN && M0 + m == 0) {  // (m is an unrolled constant)
+            if (NBR >= 4) dbacc += frag_sum<Pol>(fa);
+            else dbacc += (cb == 0 ? 1.f : 0.f) * frag_sum<Pol>(fa);
+          }
+          if (KIND == DW_HIDDEN && NBR > 4 && M0 + m == 1 && dbacc2 != nullptr) *dbacc2 += frag_sum<Pol>(fa);
+          if (KIND == DW_HEAD && M0 + m == 0) dbacc += (wave == 0 ? 1.f : 0.f) * frag_sum<Pol>(fb);
         }
       }
     }
+    Pol::drain();
   } else {
     // pinned accumulators (persistent training kernel: NBR == 4, every wave owns row block `wave`
     // and all MYB column blocks).  Fragments are fetched one k-step ahead and the schedule is fenced
     // per k-step so that no more than two k-steps of fragments are ever live.
-    static_assert(NBLK == 4 * MYB, "pinned form: every wave owns exactly MYB blocks");
+    static_assert(NBLK == 4 * MYB && M0 == 0, "pinned form: every wave owns exactly MYB blocks");
 #pragma unroll
     for (int ks = 0; ks < NKS_T; ++ks) {
 #pragma unroll
@@ -411,14 +443,14 @@ DEV void dw_gemm(const char* TA, const char* TB, f32x16 (&acc)[MYB], float& dbac
 }
 
 // write the accumulated block(s) to the flat-layout destination (plain store when `first`, else +=)
-template <class Pol, int H, int NBR, int NBC, int KIND, int MYB>
+template <class Pol, int H, int NBR, int NBC, int KIND, int MYB, int M0 = 0, bool DO_W = true, bool DO_B = true>
 DEV void dw_flush(const f32x16 (&acc)[MYB], float dbacc, float* dst_w, float* dst_b, int ldw, bool first,
                   int wave, int lane, int amode = 0) {
   constexpr int NBLK = NBR * NBC;
   const int hi = lane >> 5, j = lane & 31;
 #pragma unroll
-  for (int m = 0; m < MYB; ++m) {
-    const int blk = wave + 4 * m;
+  for (int m = 0; m < (DO_W ? MYB : 0); ++m) {
+    const int blk = wave + 4 * (M0 + m);
     if (blk < NBLK) {
       const int rbo = blk % NBR, cb = blk / NBR;
 #pragma unroll
@@ -449,7 +481,9 @@ DEV void dw_flush(const f32x16 (&acc)[MYB], float dbacc, float* dst_w, float* ds
       }
     }
   }
-  if constexpr (KIND == DW_HIDDEN) {
+  if constexpr (!DO_B) {
+    return;
+  } else if constexpr (KIND == DW_HIDDEN) {
     dbacc += __shfl_xor(dbacc, 32, 64);
     if (wave < NBR && wave < NBLK && hi == 0) {
       float* p = dst_b + 32 * (wave % NBR) + j;
@@ -473,32 +507,71 @@ template <class Pol, int H, int NBR, int NBC, int KIND>
 DEV void dw_phase(char* TA, char* TB, const float (&rows)[NBR][16], const float (&cols)[NBC][16],
                   float* dst_w, float* dst_b, int ldw, bool first, int wave, int lane, int dbg = 0) {
   constexpr int MYB = (NBR * NBC + 3) / 4;
-  constexpr int NROUND = 4 / Pol::ROUND_WAVES;
+  constexpr int NROUND = 4 / Geo<Pol, H>::ROUND_WAVES;
   const int hi = lane >> 5, j = lane & 31;
-  f32x16 acc[MYB];
-  acc_zero<MYB>(acc);
-  float dbacc = 0.f;
+  if constexpr (MYB <= 4) {
+    f32x16 acc[MYB];
+    acc_zero<MYB>(acc);
+    float dbacc = 0.f;
 #pragma unroll 1
-  for (int round = 0; round < NROUND; ++round) {
-    __syncthreads();
-    if (wave / Pol::ROUND_WAVES == round && !(dbg & 4)) {
-      t_write<Pol, H, NBR>(TA, rows, wave % Pol::ROUND_WAVES, hi, j);
-      t_write<Pol, H, NBC>(TB, cols, wave % Pol::ROUND_WAVES, hi, j);
+    for (int round = 0; round < NROUND; ++round) {
+      __syncthreads();
+      if (wave / Geo<Pol, H>::ROUND_WAVES == round && !(dbg & 4)) {
+        t_write<Pol, H, NBR>(TA, rows, wave % Geo<Pol, H>::ROUND_WAVES, hi, j);
+        t_write<Pol, H, NBC>(TB, cols, wave % Geo<Pol, H>::ROUND_WAVES, hi, j);
+      }
+      __syncthreads();
+      if (dbg & 2) continue;
+      dw_gemm<Pol, H, NBR, NBC, KIND, MYB>(TA, TB, acc, dbacc, wave, lane);
     }
-    __syncthreads();
-    if (dbg & 2) continue;
-    dw_gemm<Pol, H, NBR, NBC, KIND, MYB>(TA, TB, acc, dbacc, wave, lane);
-  }
-  if (dbg & 1) {
-    float keep = dbacc;
+    if (dbg & 1) {
+      float keep = dbacc;
 #pragma unroll
-    for (int m = 0; m < MYB; ++m)
+      for (int m = 0; m < MYB; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) keep += acc[m][r];
-    if (keep == 123.456f) dst_w[0] = keep;
-    return;
+        for (int r = 0; r < 16; ++r) keep += acc[m][r];
+      if (keep == 123.456f) dst_w[0] = keep;
+      return;
+    }
+    dw_flush<Pol, H, NBR, NBC, KIND, MYB>(acc, dbacc, dst_w, dst_b, ldw, first, wave, lane, (dbg >> 8) & 3);
+  } else {
+    // wide layers (H = 256: 16 blocks per wave): four blocks at a time, every (round, group) result is added
+    // to the partial right away -- more += traffic, bounded register use
+    static_assert(MYB % 4 == 0, "block groups of four");
+    static_assert(NBR == 8, "wide path: a wave owns row blocks w and w + 4");
+    float dbacc = 0.f, dbacc2 = 0.f;
+#pragma unroll 1
+    for (int round = 0; round < NROUND; ++round) {
+      __syncthreads();
+      if (wave / Geo<Pol, H>::ROUND_WAVES == round) {
+        t_write<Pol, H, NBR>(TA, rows, wave % Geo<Pol, H>::ROUND_WAVES, hi, j);
+        t_write<Pol, H, NBC>(TB, cols, wave % Geo<Pol, H>::ROUND_WAVES, hi, j);
+      }
+      __syncthreads();
+      const bool fw = first && round == 0;
+      auto group = [&](auto gc) {
+        constexpr int M0 = decltype(gc)::value * 4;
+        f32x16 acc[4];
+        acc_zero<4>(acc);
+        dw_gemm<Pol, H, NBR, NBC, KIND, 4, 0, M0>(TA, TB, acc, dbacc, wave, lane, &dbacc2);
+        dw_flush<Pol, H, NBR, NBC, KIND, 4, M0, true, false>(acc, 0.f, dst_w, dst_b, ldw, fw, wave, lane);
+      };
+      group(std::integral_constant<int, 0>{});
+      if constexpr (MYB > 4) group(std::integral_constant<int, 1>{});
+      if constexpr (MYB > 8) group(std::integral_constant<int, 2>{});
+      if constexpr (MYB > 12) group(std::integral_constant<int, 3>{});
+    }
+    if constexpr (KIND == DW_HIDDEN) {  // bias gradients of row blocks w and w + 4
+      dbacc += __shfl_xor(dbacc, 32, 64);
+      dbacc2 += __shfl_xor(dbacc2, 32, 64);
+      if (hi == 0) {
+        float* p0 = dst_b + 32 * wave + j;
+        float* p1 = dst_b + 32 * (wave + 4) + j;
+        *p0 = first ? dbacc : (*p0 + dbacc);
+        *p1 = first ? dbacc2 : (*p1 + dbacc2);
+      }
+    }
   }
-  dw_flush<Pol, H, NBR, NBC, KIND, MYB>(acc, dbacc, dst_w, dst_b, ldw, first, wave, lane, (dbg >> 8) & 3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -507,13 +580,14 @@ DEV void dw_phase(char* TA, char* TB, const float (&rows)[NBR][16], const float 
 enum { MODE_FWD = 0, MODE_STATS = 1, MODE_FWD_BWD = 2 };
 
 template <class Pol, int H, int MODE>
-__global__ void __launch_bounds__(256, Pol::WPS) k_reni_main(const MainArgs a) {
+__global__ void __launch_bounds__(256, (H > 128 ? 1 : Pol::WPS)) k_reni_main(const MainArgs a) {
   using G = Geo<Pol, H>;
   constexpr int NRB = G::NRB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const WB = smem;
   char* const TA = smem;  // aliases WB: the weight image is dead while a dW phase runs
   char* const TB = smem + G::WB_BYTES;
+  float* const BL = (float*)(TB + G::T_BYTES_AL);  // bias of the layer being evaluated
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -527,6 +601,28 @@ __global__ void __launch_bounds__(256, Pol::WPS) k_reni_main(const MainArgs a) {
   float* const dwp = dwp_sel;
   const int L = a.L;
   bool first = true;
+
+  // out[NRB] = image(l) x vin : the image is staged into LDS CH_RB row blocks at a time
+  auto layer_gemm = [&](const char* img, const float (&vin)[NRB][16], f32x16 (&out)[NRB], bool with_bias) {
+    auto chunk = [&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      __syncthreads();
+      if (!(a.dbg & 32)) stage_to_lds(WB, img + c * G::CHUNK_BYTES, G::CHUNK_BYTES, tid);
+      if (c == 0 && with_bias) stage_to_lds((char*)BL, img + G::IMG_HID, G::BIAS_HID, tid);
+      __syncthreads();
+      f32x16 part[G::CH_RB];
+      if (with_bias) acc_init_bias<Pol, G::CH_RB>(part, BL + 32 * G::CH_RB * c, hi);
+      else acc_zero<G::CH_RB>(part);
+      gemm_lds<Pol, G::CH_RB, NRB, G::NKS>(WB, vin, part, lane);
+#pragma unroll
+      for (int r = 0; r < G::CH_RB; ++r) out[c * G::CH_RB + r] = part[r];
+    };
+    chunk(std::integral_constant<int, 0>{});
+    if constexpr (G::NCHUNK > 1) chunk(std::integral_constant<int, 1>{});
+    if constexpr (G::NCHUNK > 2) chunk(std::integral_constant<int, 2>{});
+    if constexpr (G::NCHUNK > 3) chunk(std::integral_constant<int, 3>{});
+    static_assert(G::NCHUNK <= 4, "at most four staging chunks");
+  };
 
 #pragma unroll 1
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
@@ -583,6 +679,7 @@ __global__ void __launch_bounds__(256, Pol::WPS) k_reni_main(const MainArgs a) {
           }
         }
       }
+      Pol::drain();
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -593,12 +690,8 @@ __global__ void __launch_bounds__(256, Pol::WPS) k_reni_main(const MainArgs a) {
     // ---- hidden layers 1..L
 #pragma unroll 1
     for (int l = 1; l <= L; ++l) {
-      __syncthreads();
-      if (!(a.dbg & 32)) stage_to_lds(WB, a.wimg + a.fwd_off[l], G::IMG_HID + G::BIAS_HID, tid);
-      __syncthreads();
       f32x16 acc[NRB];
-      acc_init_bias<Pol, NRB>(acc, (const float*)(WB + G::IMG_HID), hi);
-      gemm_lds<Pol, NRB, NRB, G::NKS>(WB, v, acc, lane);
+      layer_gemm(a.wimg + a.fwd_off[l], v, acc, true);
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -610,10 +703,11 @@ __global__ void __launch_bounds__(256, Pol::WPS) k_reni_main(const MainArgs a) {
     float y[3], ylin[3], outv[3];
     {
       __syncthreads();
-      stage_to_lds(WB, a.wimg + a.fwd_off[L + 1], G::IMG_HF + G::BIAS_HEAD, tid);
+      stage_to_lds(WB, a.wimg + a.fwd_off[L + 1], G::IMG_HF, tid);
+      stage_to_lds((char*)BL, a.wimg + a.fwd_off[L + 1] + G::IMG_HF, G::BIAS_HEAD, tid);
       __syncthreads();
       f32x16 acc[1];
-      acc_init_bias<Pol, 1>(acc, (const float*)(WB + G::IMG_HF), hi);
+      acc_init_bias<Pol, 1>(acc, BL, hi);
       gemm_lds<Pol, 1, NRB, G::NKS>(WB, v, acc, lane);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -702,11 +796,7 @@ __global__ void __launch_bounds__(256, Pol::WPS) k_reni_main(const MainArgs a) {
                                 stash + (size_t)(l - 1) * G::STASH_LAYER_BYTES, tid);
         dw_phase<Pol, H, NRB, NRB, DW_HIDDEN>(TA, TB, g, hp, dwp + a.p_off_w[l], dwp + a.p_off_b[l], H, first, wave, lane, a.dbg);
       }
-      __syncthreads();
-      if (!(a.dbg & 32)) stage_to_lds(WB, a.wimg + a.bwd_off[l], G::IMG_HID, tid);
-      __syncthreads();
-      acc_zero<NRB>(acc);
-      gemm_lds<Pol, NRB, NRB, G::NKS>(WB, g, acc, lane);
+      layer_gemm(a.wimg + a.bwd_off[l], g, acc, false);
     }
     act_replay<Pol, NRB, 0>(g, acc, a.w_first, a.w_first, stash, tid);
     {
@@ -1784,6 +1874,8 @@ RENI_INST(PolF32, 128)
 RENI_INST(PolBF16, 32)
 RENI_INST(PolBF16, 64)
 RENI_INST(PolBF16, 128)
+RENI_INST(PolF32, 256)
+RENI_INST(PolBF16, 256)
 #endif  // RENI_ONLY_TRAIN
 
 }  // namespace reni

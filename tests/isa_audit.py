@@ -1,0 +1,118 @@
+"""MFMA write-back hazard audit of hipcc's gfx950 assembly (helper of test_build_audit.py).
+
+For every `v_mfma_*` the audit walks every control-flow path that leaves it and counts the wait states
+until the first instruction that touches the MFMA's destination registers and is not the next MFMA of
+the same accumulate chain.  `s_nop N` counts N + 1, every other instruction 1, a TAKEN branch 0 (the
+strict reading; hipcc's own hazard recogniser counts it as 1 and was seen to misplace its padding behind
+a block-ending MFMA -- see PolF32::drain in reni_kernels.hip).  The kernels pad their own chains, so the
+strict count must still reach the XDL write-back latency.
+
+Usage as a script:  python tests/isa_audit.py file.s
+"""
+import bisect
+import collections
+import re
+import sys
+
+# wait states an MFMA result needs before a non-chained access (MI355X ISA: passes + 4 / LLVM gfx940 tables)
+NEED = {"v_mfma_f32_32x32x16_bf16": 12, "v_mfma_f32_32x32x2_f32": 18}
+HORIZON = 24
+
+
+def _regs(tok):
+    out = set()
+    for m in re.finditer(r"\b([av])\[(\d+):(\d+)\]", tok):
+        out |= {(m.group(1), r) for r in range(int(m.group(2)), int(m.group(3)) + 1)}
+    for m in re.finditer(r"\b([av])(\d+)\b", tok):
+        out.add((m.group(1), int(m.group(2))))
+    return out
+
+
+def _states(t):
+    m = re.match(r"s_nop (\d+)", t)
+    return int(m.group(1)) + 1 if m else 1
+
+
+def parse(text):
+    labels, prog, fnames = {}, [], {}
+    for i, line in enumerate(text.split("\n")):
+        m = re.match(r"^([.\w$]+):", line)
+        if m:
+            labels[m.group(1)] = len(prog)
+            if m.group(1).startswith("_Z"):
+                fnames[len(prog)] = m.group(1)
+            continue
+        t = line.strip()
+        if not line.startswith("\t") or not t or t.startswith((".", ";")):
+            continue
+        t = t.split(";")[0].strip()
+        if t:
+            prog.append((i + 1, t))
+    return labels, prog, fnames
+
+
+def audit(text, taken_branch_states=0):
+    """-> {(function, mfma opcode): [(states, line of the MFMA, line of the access), ...]} minimal per access."""
+    labels, prog, fnames = parse(text)
+    fk = sorted(fnames)
+
+    def fn(k):
+        j = bisect.bisect_right(fk, k) - 1
+        return fnames[fk[j]] if j >= 0 else "?"
+
+    res = collections.defaultdict(list)
+    for k, (ln, t) in enumerate(prog):
+        if not t.startswith("v_mfma"):
+            continue
+        ops = t.split(None, 1)[1].split(",")
+        dtxt = ops[0].strip()
+        dest = _regs(dtxt)
+        stack, best = [(k + 1, 0)], {}
+        while stack:
+            pc, st = stack.pop()
+            while pc < len(prog) and st <= HORIZON:
+                if best.get(pc, 1 << 30) <= st:
+                    break
+                best[pc] = st
+                l2, t2 = prog[pc]
+                op = t2.split()[0]
+                if op == "s_endpgm":
+                    break
+                if op.startswith("v_mfma"):
+                    o2 = t2.split(None, 1)[1].split(",")
+                    chained = (o2[0].strip() == dtxt and o2[-1].strip().split()[0] == dtxt
+                               and not (_regs(o2[1]) | _regs(o2[2])) & dest)
+                    if chained:
+                        break  # back-to-back accumulate: no wait needed, the chain restarts from that MFMA
+                if op == "s_branch" or op.startswith("s_cbranch"):
+                    tgt = t2.split()[1]
+                    if tgt in labels:
+                        stack.append((labels[tgt], st + taken_branch_states))
+                    if op == "s_branch":
+                        break
+                    pc += 1
+                    st += 1
+                    continue
+                if _regs(t2) & dest:
+                    res[(fn(k), t.split()[0])].append((st, ln, l2))
+                    break
+                st += _states(t2)
+                pc += 1
+    return res
+
+
+def violations(text, skip=("k_probe",)):
+    bad = []
+    for (f, kind), v in audit(text).items():
+        if any(s in f for s in skip) or kind not in NEED:
+            continue
+        bad += [(f, kind, st, a, b) for st, a, b in v if st < NEED[kind]]
+    return bad
+
+
+if __name__ == "__main__":
+    txt = open(sys.argv[1]).read()
+    for (f, kind), v in sorted(audit(txt).items()):
+        print(f[:70].ljust(70), kind[7:], "min states", min(x[0] for x in v), "accesses", len(v))
+    for b in violations(txt):
+        print("VIOLATION", b)

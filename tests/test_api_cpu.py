@@ -34,6 +34,7 @@ def test_plan_validation_and_counts():
     assert p1.n_params == 19203 and p1.in_features == 101
     assert Plan("SO3", 49, 128, 5).in_features == 2450
     assert Plan("None", 9, 64, 3).in_features == 36
+    assert Plan("SO2", 36, 256, 5).n_params == 256 * 1370 + 256 + 5 * (256 * 256 + 256) + 3 * 256 + 3  # reference default width
     assert p.lib.reni_workspace_bytes(p._h, 4, 32768, 3) > 0
     with pytest.raises(_lib.RENILibraryError, match="hidden_features"):
         Plan("SO2", 9, 100, 3)

@@ -9,6 +9,8 @@ import re
 import subprocess
 import tempfile
 
+from tests import isa_audit
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -42,3 +44,23 @@ def test_training_kernel_agprs_only_in_hand_written_asm():
     assert mfma > 100 and touching >= 512
     assert outside == 0, f"{outside} compiler-generated instructions touch AGPRs"
     assert scratch == 0, f"{scratch} scratch (spill) instructions in the training kernel"
+
+
+def test_mfma_results_are_never_read_before_their_write_back():
+    """Every MFMA of every kernel: strict wait-state count (taken branches count 0) to the first
+    non-chained access of its result reaches the XDL write-back latency.  Guards against the hipcc
+    hazard-padding defect that produced nondeterministic H = 256 head gradients (tests/isa_audit.py)."""
+    src = os.path.join(ROOT, "reni_amd", "csrc", "reni_kernels.hip")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "all.s")
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                        "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
+                        "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), src, "-o", out],
+                       check=True, capture_output=True)
+        text = open(out).read()
+    res = isa_audit.audit(text)
+    kernels = {f for f, _ in res}
+    assert any("k_reni_train_bf16" in f for f in kernels) and any("k_reni_main" in f for f in kernels)
+    bad = isa_audit.violations(text)
+    assert not bad, "MFMA result accessed too early: " + "; ".join(
+        f"{f[:48]} {k} {st} states (asm lines {a}->{b})" for f, k, st, a, b in bad[:8])
