@@ -50,6 +50,10 @@ extern "C" {
 #define RENI_F32 0  /* fp32 MFMA (v_mfma_f32_32x32x2_f32), precise sin/cos: bit-for-bit an fmaf chain */
 #define RENI_BF16 1 /* bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate, fp32 sin argument    */
 
+/* reni_desc.conditioning : how the latent code conditions the SIREN (src/models/RENI.py:862, 877-933) */
+#define RENI_COND_CONCAT 0 /* Cond-by-Concat: RENIAutoDecoder / RENIVariationalAutoDecoder      RENI.py:90-399  */
+#define RENI_COND_FILM 1   /* FiLM: RENIAutoDecoderFiLM / RENIVariationalAutoDecoderFiLM         RENI.py:407-858 */
+
 /* loss_kind for reni_forward_loss_backward */
 #define RENI_LOSS_MSE 0  /* RENITrainLoss      = WeightedMSE                  loss_functions.py:6-13,39-45 */
 #define RENI_LOSS_TEST 1 /* RENITestLoss       = MSE + alpha*|Z|^2 + beta*WeightedCosine  :25-32,60-71     */
@@ -71,6 +75,8 @@ typedef struct reni_desc {
   float first_omega_0;       /*                                             RENI.py:139     */
   float hidden_omega_0;      /*                                             RENI.py:149     */
   int32_t dtype;             /* RENI_F32 | RENI_BF16 */
+  int32_t conditioning;      /* RENI_COND_*.  FiLM: hidden_layers = siren_hidden_layers - 1 (RENI.py:563-568),
+                                omegas unused, last_layer_linear = 1                     RENI.py:537-570 */
 } reni_desc;
 
 /* Message of the last error raised on this thread ("" if none). */
@@ -121,6 +127,34 @@ int reni_forward_loss_backward(const reni_plan* plan, int64_t B, int64_t P, cons
 int reni_backward(const reni_plan* plan, int64_t B, int64_t P, const float* Z, const float* D,
                   int64_t d_batch_stride, const float* params, const float* dout, uint32_t flags,
                   float* dZ, float* dparams, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- FiLM conditioning (src/models/RENI.py:407-858) ------------------------------------------------
+ * The per-SAMPLE work of RENI*FiLM.forward_with_frequencies_phase_shifts (RENI.py:665-676, FiLMLayer
+ * :508-519) runs in the fused kernels; the per-IMAGE glue stays with the caller (reni_amd/film.py):
+ *   - the mapping network (RENI.py:470-505) is evaluated once per image -- the reference evaluates it per
+ *     pixel on repeated rows (RENI.py:413-447), same values -- giving freq = 15 f + 30 and phase (RENI.py:666);
+ *   - the first FiLMLayer acts on Siren_Input = [|d_xz|, d_y, D_xz Z_xz^T] (SO2, RENI.py:441) or D Z^T (SO3,
+ *     RENI.py:410), which is linear in (dx, dy, dz, r): theta_0 = A_b (dx, dy, dz, r, 1) with the per-image
+ *     A [B,H,8] (columns dx, dy, dz, r, 1, 3 unused) = freq_0 . (W_0 x + b_0) + phase_0 folded by the caller.
+ * Flat `params`: net.0.layer.weight [H,F0], net.0.layer.bias [H] (unused by the kernels), net.l.layer.weight
+ * [H,H], .bias [H] for l = 1..L, final_layer.weight [3,H], .bias [3];  F0 = reni_in_features().
+ * film [B,L,2,H]: film[b][l-1][0] = freq, [1] = phase of hidden FiLM layer l of image b.
+ * Gradients: dA [B,H,8] (d loss / d A), dfilm [B,L,2,H], dparams (flat; the net.0 slot is zero-filled --
+ * its gradient follows from dA in the caller's glue).  loss_terms = (mse + cosine, mse, 0, cosine): the
+ * latent prior of RENITestLoss (alpha |Z|^2) is the caller's. */
+int reni_film_forward(const reni_plan* plan, int64_t B, int64_t P, const float* D, int64_t d_batch_stride,
+                      const float* A, const float* film, const float* params, float* out, void* ws,
+                      size_t ws_bytes, void* stream);
+int reni_film_forward_loss_backward(const reni_plan* plan, int64_t B, int64_t P, const float* D,
+                                    int64_t d_batch_stride, const float* A, const float* film,
+                                    const float* params, const float* target, const int64_t tgt_strides[3],
+                                    const float* weight, const int64_t w_strides[3], int32_t loss_kind,
+                                    float beta, uint32_t flags, float* out, float* loss_terms, float* dA,
+                                    float* dfilm, float* dparams, void* ws, size_t ws_bytes, void* stream);
+int reni_film_backward(const reni_plan* plan, int64_t B, int64_t P, const float* D, int64_t d_batch_stride,
+                       const float* A, const float* film, const float* params, const float* dout,
+                       uint32_t flags, float* dA, float* dfilm, float* dparams, void* ws, size_t ws_bytes,
+                       void* stream);
 
 /* torch.optim.Adam(lr, betas=(b1,b2), eps) step on a flat buffer (RENI_module.py:192: the
  * reference always uses the default betas (0.9, 0.999), eps 1e-8).  `step` is the 1-based step

@@ -484,6 +484,131 @@ def factored_fwd_bwd(spec: DecoderSpec, params: Dict[str, np.ndarray], Z: np.nda
 
 
 # --------------------------------------------------------------------------------------
+# FiLM conditioning  (src/models/RENI.py:407-858)   -- pinned by tests/golden/g11_film_*.npz
+# --------------------------------------------------------------------------------------
+
+
+class FilmSpec:
+    """Hyper-parameters of RENIAutoDecoderFiLM / RENIVariationalAutoDecoderFiLM (RENI.py:522-598):
+    ``siren_hidden_layers`` is the TOTAL number of FiLM layers (RENI.py:563-568)."""
+
+    def __init__(self, ndims, equivariance="SO2", siren_hidden_features=128, siren_hidden_layers=5,
+                 mapping_network_features=128, mapping_network_layers=3, out_features=3, output_activation="tanh"):
+        assert equivariance in ("SO2", "SO3"), "the reference's None-FiLM encoding cannot run (RENI.py:449-452 vs :552-555)"
+        self.ndims = ndims
+        self.equivariance = equivariance
+        self.H = siren_hidden_features
+        self.n_film = siren_hidden_layers
+        self.map_features = mapping_network_features
+        self.map_layers = mapping_network_layers
+        self.out_features = out_features
+        self.output_activation = output_activation
+        self.in_features = 2 + ndims if equivariance == "SO2" else ndims            # RENI.py:556-561
+        self.mn_in_features = ndims * ndims + ndims if equivariance == "SO2" else ndims * ndims
+
+    def param_keys(self) -> List[str]:
+        keys = []
+        for i in range(self.n_film):
+            keys += [f"net.{i}.layer.weight", f"net.{i}.layer.bias"]
+        keys += ["final_layer.weight", "final_layer.bias"]
+        for i in range(self.map_layers + 1):
+            keys += [f"mapping_network.network.{2 * i}.weight", f"mapping_network.network.{2 * i}.bias"]
+        return keys
+
+
+def film_encode(spec: FilmSpec, Z: torch.Tensor, D: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(Siren_Input [B,P,F0], Mapping_Input [B,M]) -- RENI.py:407-447.  The reference repeats the mapping
+    input for every pixel; it is constant per image, so one row per image is returned here."""
+    if spec.equivariance == "SO3":
+        G = Z @ Z.transpose(1, 2)
+        return torch.bmm(D, Z.transpose(1, 2)), G.flatten(start_dim=1)
+    Z_xz = torch.stack((Z[:, :, 0], Z[:, :, 2]), -1)
+    D_xz = torch.stack((D[:, :, 0], D[:, :, 2]), -1)
+    G = torch.bmm(Z_xz, Z_xz.transpose(1, 2))
+    innerprod = torch.bmm(D_xz, Z_xz.transpose(1, 2))
+    D_xz_norm = torch.sqrt(D[:, :, 0] ** 2 + D[:, :, 2] ** 2).unsqueeze(2)
+    D_y = D[:, :, 1].unsqueeze(2)
+    return torch.cat((D_xz_norm, D_y, innerprod), 2), torch.cat((G.flatten(start_dim=1), Z[:, :, 1]), 1)
+
+
+def film_mapping(spec: FilmSpec, params: Dict[str, torch.Tensor], m: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """CustomMappingNetwork.forward (RENI.py:470-505): Linear + LeakyReLU(0.2) x layers, Linear; split in halves."""
+    x = m
+    for i in range(spec.map_layers):
+        x = torch.nn.functional.leaky_relu(
+            torch.nn.functional.linear(x, params[f"mapping_network.network.{2 * i}.weight"],
+                                       params[f"mapping_network.network.{2 * i}.bias"]), 0.2)
+    i = spec.map_layers
+    fo = torch.nn.functional.linear(x, params[f"mapping_network.network.{2 * i}.weight"],
+                                    params[f"mapping_network.network.{2 * i}.bias"])
+    half = fo.shape[-1] // 2
+    return fo[..., :half], fo[..., half:]
+
+
+def film_forward(spec: FilmSpec, params: Dict[str, torch.Tensor], Z: torch.Tensor, D: torch.Tensor) -> torch.Tensor:
+    """RENI*FiLM.forward on a latent tensor (RENI.py:654-676): x <- sin(freq . (W x + b) + phase) per FiLM
+    layer with freq = 15 f + 30, then final_layer and the output activation."""
+    if D.shape[0] == 1 and Z.shape[0] != 1:
+        D = D.expand(Z.shape[0], -1, -1)
+    x, m = film_encode(spec, Z, D)
+    f, ph = film_mapping(spec, params, m)
+    f = f * 15 + 30
+    H = spec.H
+    for i in range(spec.n_film):
+        a = torch.nn.functional.linear(x, params[f"net.{i}.layer.weight"], params[f"net.{i}.layer.bias"])
+        x = torch.sin(f[:, None, i * H:(i + 1) * H] * a + ph[:, None, i * H:(i + 1) * H])
+    y = torch.nn.functional.linear(x, params["final_layer.weight"], params["final_layer.bias"])
+    if spec.output_activation == "tanh":
+        return torch.tanh(y)
+    if spec.output_activation == "exp":
+        return torch.exp(y)
+    return y
+
+
+def film_fwd_loss_bwd(spec: FilmSpec, params: Dict[str, torch.Tensor], Z: torch.Tensor, D: torch.Tensor,
+                      target: torch.Tensor, weight: torch.Tensor, loss_kind: str = "mse", alpha: float = 0.0,
+                      beta: float = 0.0) -> Dict[str, object]:
+    """Autograd reference of one FiLM training / latent-fitting step."""
+    ps = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    Zr = Z.detach().clone().requires_grad_(True)
+    out = film_forward(spec, ps, Zr, D)
+    B = Z.shape[0]
+    if loss_kind == "mse":
+        terms = (train_loss(out, target.expand(B, -1, -1), weight.expand(B, -1, -1)),)
+    else:
+        terms = test_loss(out, target.expand(B, -1, -1), weight.expand(B, -1, -1), Zr, alpha, beta)
+    terms[0].backward()
+    return {"out": out.detach(), "terms": [float(t.detach()) for t in terms], "dZ": Zr.grad.detach(),
+            "grads": {k: (v.grad.detach() if v.grad is not None else torch.zeros_like(v)) for k, v in ps.items()}}
+
+
+def film_init_params(spec: FilmSpec, generator: Optional[torch.Generator] = None) -> Dict[str, torch.Tensor]:
+    """Random parameters with the reference's distributions (RENI.py:455-498, 574-576); NOT the reference's
+    RNG stream (seed parity is the product module's job and is tested against the goldens)."""
+    g = generator
+    H, out = spec.H, {}
+
+    def U(shape, b):
+        return (torch.rand(shape, generator=g) * 2 - 1) * b
+
+    for i in range(spec.n_film):
+        fin = spec.in_features if i == 0 else H
+        out[f"net.{i}.layer.weight"] = U((H, fin), 1 / fin if i == 0 else math.sqrt(6 / fin) / 25)
+        out[f"net.{i}.layer.bias"] = U((H,), 1 / math.sqrt(fin))
+    out["final_layer.weight"] = U((spec.out_features, H), math.sqrt(6 / H) / 25)
+    out["final_layer.bias"] = U((spec.out_features,), 1 / math.sqrt(H))
+    fin = spec.mn_in_features
+    for i in range(spec.map_layers + 1):
+        fout = spec.map_features if i < spec.map_layers else 2 * spec.n_film * H
+        std = math.sqrt(2.0 / (1 + 0.2 ** 2)) / math.sqrt(fin)
+        w = torch.randn((fout, fin), generator=g) * std
+        out[f"mapping_network.network.{2 * i}.weight"] = w * (0.25 if i == spec.map_layers else 1.0)
+        out[f"mapping_network.network.{2 * i}.bias"] = U((fout,), 1 / math.sqrt(fin))
+        fin = fout
+    return out
+
+
+# --------------------------------------------------------------------------------------
 # helpers shared by tests / bench (synthetic inputs of SURVEY.md section 8d)
 # --------------------------------------------------------------------------------------
 

@@ -19,12 +19,14 @@ ACT = {None: 0, "None": 0, "none": 0, "tanh": 1, "exp": 2}
 DTYPE = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 LOSS_MSE, LOSS_TEST = 0, 1
 NEED_DW, NEED_DZ = 1, 2
+COND_CONCAT, COND_FILM = 0, 1
 
 # every symbol include/reni_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
     "reni_last_error", "reni_plan_create", "reni_plan_destroy", "reni_param_count", "reni_in_features",
     "reni_workspace_bytes", "reni_forward", "reni_forward_loss_backward", "reni_backward",
     "reni_adam_step", "reni_selftest_layouts", "reni_launch_info", "reni_profile_enable", "reni_profile_read", "reni_probe_tr",
+    "reni_film_forward", "reni_film_forward_loss_backward", "reni_film_backward",
 )
 
 
@@ -33,7 +35,7 @@ class reni_desc(Structure):
         ("equivariance", c_int32), ("ndims", c_int32), ("hidden_features", c_int32),
         ("hidden_layers", c_int32), ("out_features", c_int32), ("last_layer_linear", c_int32),
         ("output_activation", c_int32), ("first_omega_0", c_float), ("hidden_omega_0", c_float),
-        ("dtype", c_int32),
+        ("dtype", c_int32), ("conditioning", c_int32),
     ]
 
 
@@ -78,6 +80,16 @@ def load():
     lib.reni_backward.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                   c_uint32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.reni_backward.restype = c_int32
+    lib.reni_film_forward.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.reni_film_forward.restype = c_int32
+    lib.reni_film_forward_loss_backward.argtypes = [
+        c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, i64x3, c_void_p, i64x3,
+        c_int32, c_float, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.reni_film_forward_loss_backward.restype = c_int32
+    lib.reni_film_backward.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.reni_film_backward.restype = c_int32
     lib.reni_adam_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                    c_float, c_int64, c_float, c_void_p]
     lib.reni_adam_step.restype = c_int32

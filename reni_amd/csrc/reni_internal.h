@@ -1,5 +1,6 @@
 // reni_internal.h -- kernel argument blocks shared by reni_kernels.hip and reni_capi.inc
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -39,7 +40,19 @@ struct MainArgs {
   float* loss_part;  // [n_tiles][4][16]
   char* g1;          // [n_tiles][H/16][256][16 B] bf16 g_1 stream (persistent training path)
   long long* trace;  // optional (tag, s_memtime) pairs from workgroup 0 (RENI_TRACE builds)
+  // FiLM conditioning (k_reni_main<..., FILM = true>): hidden layer l in 1..L of image b applies
+  // sin(freq . (W_l h + b_l) + phase); film[b][l-1][0][.] = freq, [1][.] = phase
+  const float* film;
+  float* dfp_part;      // [n_tiles][L][2][H] per-tile d(freq), d(phase)
+  const float* params;  // flat fp32 parameters (d(freq) needs W_l and b_l)
+  unsigned n_first;     // p_off_* are relative to the partial buffer: params offset = p_off + n_first
 };
+
+// host launchers of the fused kernel, one per translation unit (reni_device.inc)
+hipError_t launch_main_f32(int H, int mode, const MainArgs& a, int nwg, hipStream_t s);
+hipError_t launch_main_bf16(int H, int mode, const MainArgs& a, int nwg, hipStream_t s);
+hipError_t launch_film_f32(int H, int mode, const MainArgs& a, int nwg, hipStream_t s);
+hipError_t launch_film_bf16(int H, int mode, const MainArgs& a, int nwg, hipStream_t s);
 
 struct PrepArgs {
   const float* Z;

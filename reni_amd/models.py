@@ -376,9 +376,7 @@ class RENIVariationalAutoDecoder(_RENIConcatBase):
 
 def get_model(config, dataset_size, task):
     """config -> model (src/models/RENI.py:861-933).  ``config`` is any object exposing
-    ``config.RENI.<KEY>`` attributes (yacs CfgNode, SimpleNamespace, ...).  Only the
-    Cond-by-Concat family is built here; FiLM conditioning is outside this round's scope
-     and raises."""
+    ``config.RENI.<KEY>`` attributes (yacs CfgNode, SimpleNamespace, ...)."""
     r = config.RENI
     fixed_decoder = True if task in ["FIT_LATENT", "FIT_INVERSE"] else False  # RENI.py:874
     if r.CONDITIONING == "Cond-by-Concat":
@@ -393,5 +391,14 @@ def get_model(config, dataset_size, task):
             model.set_compute_dtype(dtype)
         return model
     if r.CONDITIONING == "FiLM":
-        raise NotImplementedError("FiLM-conditioned RENI variants are not part of this build (SURVEY.md 8 f1)")
+        from .film import RENIAutoDecoderFiLM, RENIVariationalAutoDecoderFiLM
+        cls = {"AutoDecoder": RENIAutoDecoderFiLM, "VariationalAutoDecoder": RENIVariationalAutoDecoderFiLM}.get(r.MODEL_TYPE)
+        if cls is None:
+            return None
+        model = cls(dataset_size, r.LATENT_DIMENSION, r.EQUIVARIANCE, r.HIDDEN_FEATURES, r.HIDDEN_LAYERS,
+                    r.MAPPING_FEATURES, r.MAPPING_LAYERS, r.OUT_FEATURES, r.OUTPUT_ACTIVATION, fixed_decoder)
+        dtype = getattr(r, "COMPUTE_DTYPE", None)
+        if dtype:
+            model.set_compute_dtype(dtype)
+        return model
     return None

@@ -30,7 +30,8 @@ class Plan:
 
     def __init__(self, equivariance: str, ndims: int, hidden_features: int, hidden_layers: int,
                  out_features: int = 3, last_layer_linear: bool = True, output_activation=None,
-                 first_omega_0: float = 30.0, hidden_omega_0: float = 30.0, dtype: str = "f32"):
+                 first_omega_0: float = 30.0, hidden_omega_0: float = 30.0, dtype: str = "f32",
+                 conditioning: str = "concat"):
         lib = _lib.load()
         if equivariance not in _lib.EQ:
             raise ValueError(f"equivariance {equivariance!r}")
@@ -38,7 +39,11 @@ class Plan:
             raise ValueError(f"output_activation {output_activation!r}")
         self.desc = _lib.reni_desc(_lib.EQ[equivariance], ndims, hidden_features, hidden_layers, out_features,
                                    1 if last_layer_linear else 0, _lib.ACT[output_activation],
-                                   float(first_omega_0), float(hidden_omega_0), _lib.DTYPE[dtype])
+                                   float(first_omega_0), float(hidden_omega_0), _lib.DTYPE[dtype],
+                                   {"concat": _lib.COND_CONCAT, "film": _lib.COND_FILM}[conditioning])
+        self.conditioning = conditioning
+        self.hidden_features = hidden_features
+        self.hidden_layers = hidden_layers
         self._h = ctypes.c_void_p()
         _lib.check(lib.reni_plan_create(ctypes.byref(self.desc), ctypes.byref(self._h)))
         self.lib = lib
@@ -154,6 +159,85 @@ class Plan:
             dZ.data_ptr() if dZ is not None else None, dparams.data_ptr() if dparams is not None else None,
             wp, wn, stream))
         return dZ, dparams
+
+
+    # ---- FiLM conditioning: the per-sample core (per-image glue in reni_amd/film.py)
+    def _film_args(self, A, film, D):
+        B = A.shape[0]
+        H, L = self.hidden_features, self.hidden_layers
+        assert A.shape == (B, H, 8), f"A must be [B,{H},8], got {tuple(A.shape)}"
+        assert film.shape == (B, L, 2, H), f"film must be [B,{L},2,{H}], got {tuple(film.shape)}"
+        if D.dim() == 2:
+            D = D.unsqueeze(0)
+        if D.shape[0] not in (1, B):
+            raise ValueError(f"directions batch {D.shape[0]} does not match latent batch {B}")
+        P = D.shape[1]
+        dbs = 0 if D.shape[0] == 1 or D.stride(0) == 0 else P * 3
+        if dbs == 0:
+            D = D[:1]
+        return B, P, _f32c(D), dbs
+
+    def film_forward(self, A, film, D, params):
+        _require_cuda(A, film, D, params)
+        A = _f32c(A); film = _f32c(film); params = _f32c(params)
+        B, P, Dc, dbs = self._film_args(A, film, D)
+        assert params.numel() == self.n_params
+        out = torch.empty(B, P, 3, dtype=torch.float32, device=A.device)
+        ws = self.workspace(B, P, 0, A.device)
+        wp, wn = self._aligned_ptr(ws)
+        stream = torch.cuda.current_stream(A.device).cuda_stream
+        _lib.check(self.lib.reni_film_forward(self._h, B, P, Dc.data_ptr(), dbs, A.data_ptr(), film.data_ptr(),
+                                              params.data_ptr(), out.data_ptr(), wp, wn, stream))
+        return out
+
+    def film_forward_loss_backward(self, A, film, D, params, target, weight, loss_kind="mse", beta=0.0,
+                                   need_dw=True, want_out=False):
+        """-> (loss_terms[4], dA [B,H,8], dfilm [B,L,2,H], dparams or None, out or None)"""
+        _require_cuda(A, film, D, params, target, weight)
+        A = _f32c(A); film = _f32c(film); params = _f32c(params)
+        B, P, Dc, dbs = self._film_args(A, film, D)
+        if target.dtype != torch.float32:
+            target = target.float()
+        if weight.dtype != torch.float32:
+            weight = weight.float()
+        target = target.expand(B, P, 3)
+        weight = weight.expand(B, P, 3)
+        ts = (ctypes.c_int64 * 3)(*target.stride())
+        wst = (ctypes.c_int64 * 3)(*weight.stride())
+        flags = _lib.NEED_DW if need_dw else 0
+        dev = A.device
+        loss_terms = torch.empty(4, dtype=torch.float32, device=dev)
+        dA = torch.empty_like(A)
+        dfilm = torch.empty_like(film)
+        dparams = torch.empty(self.n_params, dtype=torch.float32, device=dev) if need_dw else None
+        out = torch.empty(B, P, 3, dtype=torch.float32, device=dev) if want_out else None
+        ws = self.workspace(B, P, flags, dev)
+        wp, wn = self._aligned_ptr(ws)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        kind = {"mse": _lib.LOSS_MSE, "test": _lib.LOSS_TEST}[loss_kind]
+        _lib.check(self.lib.reni_film_forward_loss_backward(
+            self._h, B, P, Dc.data_ptr(), dbs, A.data_ptr(), film.data_ptr(), params.data_ptr(), target.data_ptr(), ts,
+            weight.data_ptr(), wst, kind, float(beta), flags, out.data_ptr() if out is not None else None,
+            loss_terms.data_ptr(), dA.data_ptr(), dfilm.data_ptr(),
+            dparams.data_ptr() if dparams is not None else None, wp, wn, stream))
+        return loss_terms, dA, dfilm, dparams, out
+
+    def film_backward(self, A, film, D, params, dout, need_dw=True):
+        _require_cuda(A, film, D, params, dout)
+        A = _f32c(A); film = _f32c(film); params = _f32c(params); dout = _f32c(dout)
+        B, P, Dc, dbs = self._film_args(A, film, D)
+        flags = _lib.NEED_DW if need_dw else 0
+        dev = A.device
+        dA = torch.empty_like(A)
+        dfilm = torch.empty_like(film)
+        dparams = torch.empty(self.n_params, dtype=torch.float32, device=dev) if need_dw else None
+        ws = self.workspace(B, P, flags, dev)
+        wp, wn = self._aligned_ptr(ws)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(self.lib.reni_film_backward(
+            self._h, B, P, Dc.data_ptr(), dbs, A.data_ptr(), film.data_ptr(), params.data_ptr(), dout.data_ptr(), flags,
+            dA.data_ptr(), dfilm.data_ptr(), dparams.data_ptr() if dparams is not None else None, wp, wn, stream))
+        return dA, dfilm, dparams
 
 
 def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,

@@ -321,8 +321,48 @@ def g10():
     save("g10_equivariance.npz", **out)
 
 
+# ---------------------------------------------------------------- G11 FiLM conditioning
+def g11():
+    """RENI*FiLM (src/models/RENI.py:407-858): seeded state dicts, per-image frequencies / phase shifts,
+    forward, RENITrainLoss gradients of every parameter and of Z, and a RENITestLoss latent gradient."""
+    W = 32
+    D = ref_utils.get_directions(W).repeat(2, 1, 1)
+    s = ref_utils.get_sineweight(W).repeat(2, 1, 1)
+    t = synth_targets(2, D.shape[1], 110)
+    cases = {
+        # tag: (class, eq, H, siren layers, mapping features, mapping layers, activation)
+        "so2_ad": (ref.RENIAutoDecoderFiLM, "SO2", 64, 3, 32, 2, "tanh"),
+        "so3_vad": (ref.RENIVariationalAutoDecoderFiLM, "SO3", 64, 2, 48, 1, "exp"),
+        "so2_one": (ref.RENIAutoDecoderFiLM, "SO2", 32, 1, 16, 1, None),
+    }
+    for tag, (cls, eq, H, nF, mf, ml, act) in cases.items():
+        torch.manual_seed(111)
+        m = cls(2, 9, eq, H, nF, mf, ml, 3, act, False)
+        Z = (m.Z if hasattr(m, "Z") else m.mu).detach().clone() * 0.5
+        for prm in m.parameters():
+            prm.grad = None
+        Zr = Z.clone().requires_grad_(True)
+        si, mi = m.InvariantRepresentation(Zr, D)
+        fr, ph = m.mapping_network(mi)
+        out = m(Zr, D)
+        loss = ref_loss.RENITrainLoss()(out, t, s)
+        loss.backward()
+        arrs = {"sd." + k: v for k, v in sd_np(m).items()}
+        arrs.update({"g." + k: prm.grad.numpy().copy() for k, prm in m.named_parameters()
+                     if prm.grad is not None and k not in ("Z", "mu", "log_var")})
+        # RENITestLoss on the same model (latent gradient only)
+        Z2 = Z.clone().requires_grad_(True)
+        tl = ref_loss.RENITestLoss(alpha=1e-3, beta=1e-1)(m(Z2, D), t, s, Z2)
+        tl[0].backward()
+        save(f"g11_film_{tag}.npz", Z=Z.numpy(), target=t.numpy(), out=out.detach().numpy(), loss=loss.detach().numpy(),
+             dZ=Zr.grad.numpy(), freq_raw=fr[:, 0].detach().numpy(), phase=ph[:, 0].detach().numpy(),
+             siren_input_head=si[:, :8].detach().numpy(), test_terms=np.array([x.item() for x in tl]),
+             test_dZ=Z2.grad.numpy(), W=np.int64(W),
+             cfg=np.array([{"SO2": 1, "SO3": 2}[eq], 9, H, nF, mf, ml, {None: 0, "tanh": 1, "exp": 2}[act]]), **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()

@@ -13,6 +13,10 @@ from reni_amd import _lib, utils
 from reni_amd.models import RENIAutoDecoder, RENIVariationalAutoDecoder, get_model
 from tests.util import load_golden
 
+
+def load_golden_sd(g):
+    return {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -122,8 +126,64 @@ def test_get_model_factory():
     m = get_model(_cfg(MODEL_TYPE="VariationalAutoDecoder"), 7, "FIT_LATENT")
     assert isinstance(m, RENIVariationalAutoDecoder) and m.fixed_decoder
     assert float(m.mu.abs().sum()) == 0.0
+    from reni_amd.film import RENIAutoDecoderFiLM, RENIVariationalAutoDecoderFiLM
+    m = get_model(_cfg(CONDITIONING="FiLM"), 7, "FIT_DECODER")
+    assert isinstance(m, RENIAutoDecoderFiLM) and len(m.net) == 3 and m.mapping_network.network[0].in_features == 90
+    m = get_model(_cfg(CONDITIONING="FiLM", MODEL_TYPE="VariationalAutoDecoder"), 7, "FIT_INVERSE")
+    assert isinstance(m, RENIVariationalAutoDecoderFiLM) and m.fixed_decoder
+    assert not any(p.requires_grad for p in list(m.net.parameters()) + list(m.mapping_network.parameters()))
+
+
+@pytest.mark.parametrize("tag", ["so2_ad", "so3_vad", "so2_one"])
+def test_film_state_dict_seed_parity_and_glue(golden, tag):
+    """FiLM modules: the reference's state-dict keys and, for the same torch seed, bit-identical initial values
+    (RENI.py:563-596 RNG order); the per-image glue reproduces the reference's frequencies / phase shifts and the
+    first layer's angle."""
+    from reni_amd.film import RENIAutoDecoderFiLM, RENIVariationalAutoDecoderFiLM
+    g = golden(f"g11_film_{tag}.npz")
+    eq, nd, H, nF, mf, ml, act = [int(x) for x in g["cfg"]]
+    cls = RENIVariationalAutoDecoderFiLM if "sd.mu" in g else RENIAutoDecoderFiLM
+    torch.manual_seed(111)
+    m = cls(2, nd, {1: "SO2", 2: "SO3"}[eq], H, nF, mf, ml, 3, {0: None, 1: "tanh", 2: "exp"}[act], False)
+    sd = m.state_dict()
+    want = load_golden_sd(g)
+    assert sorted(sd) == sorted(want)
+    for k in want:
+        assert torch.equal(sd[k], want[k]), k
+    # flat storage: net.* then final_layer.* back the C ABI's `params`
+    flat = m._flat_params()
+    assert flat.numel() == sum(p.numel() for p in m._net_params()) and m.net[0].layer.weight.data_ptr() == flat.data_ptr()
+    Z = torch.from_numpy(g["Z"])
+    A, film = m._glue(Z)
+    assert A.shape == (2, H, 8) and film.shape == (2, nF - 1, 2, H)
+    fr = torch.from_numpy(g["freq_raw"]) * 15 + 30
+    ph = torch.from_numpy(g["phase"])
+    if nF > 1:
+        assert float((film[:, :, 0].reshape(2, -1) - fr[:, H:]).abs().max()) <= 1e-5
+        assert float((film[:, :, 1].reshape(2, -1) - ph[:, H:]).abs().max()) <= 1e-6
+    si = torch.from_numpy(g["siren_input_head"])
+    th_ref = fr[:, None, :H] * (si @ sd["net.0.layer.weight"].t() + sd["net.0.layer.bias"]) + ph[:, None, :H]
+    D = utils.get_directions(int(g["W"]))[0, :8]
+    x5 = torch.stack([D[:, 0], D[:, 1], D[:, 2], torch.sqrt(D[:, 0] ** 2 + D[:, 2] ** 2), torch.ones(8)], -1)
+    assert float((torch.einsum("bhk,pk->bph", A[:, :, :5], x5) - th_ref).abs().max()) <= 2e-5
+    with pytest.raises(_lib.RENILibraryError, match="no CPU fallback"):
+        m(Z, D[None].repeat(2, 1, 1))
+
+
+def test_film_plan_validation():
+    from reni_amd.film import RENIAutoDecoderFiLM
+    from reni_amd.ops import Plan
+    p = Plan("SO2", 9, 64, 2, 3, True, "tanh", dtype="bf16", conditioning="film")
+    assert p.in_features == 11 and p.n_params == 64 * 11 + 64 + 2 * (64 * 64 + 64) + 3 * 64 + 3
+    assert Plan("SO3", 9, 64, 0, conditioning="film").in_features == 9
+    with pytest.raises(_lib.RENILibraryError, match="None"):
+        Plan("None", 9, 64, 2, conditioning="film")
+    lib = p.lib
+    assert lib.reni_forward(p._h, 1, 128, 8, 8, 0, 8, 8, 256, 0, None) == -1 and b"reni_film" in lib.reni_last_error()
+    assert lib.reni_film_forward(p._h, 1, 128, 8, 0, None, 8, 8, 8, 256, 0, None) == -1
+    m = RENIAutoDecoderFiLM(2, 9, "None", 64, 2, 32, 1, 3, None, False)  # constructible, as in the reference ...
     with pytest.raises(NotImplementedError):
-        get_model(_cfg(CONDITIONING="FiLM"), 7, "FIT_DECODER")
+        m._plan()                                                          # ... but never runnable
 
 
 def test_vad_sample_latent_matches_reference_stream(golden):

@@ -1,7 +1,7 @@
 """CPU-side audit of the emitted gfx950 ISA (hipcc cross-compiles without a GPU).
 
 The persistent bf16 training kernel owns all 256 AGPRs by hand (sixteen literal accumulator tiles,
-reni_amd/csrc/reni_kernels.hip: mfma_bf16_agpr_tile).  That is only sound if NO compiler-generated
+reni_amd/csrc/reni_device.inc: mfma_bf16_agpr_tile).  That is only sound if NO compiler-generated
 instruction of that kernel touches an AGPR and the kernel does not spill.  Both are checked here on the
 assembly hipcc emits, so an edit that breaks the invariant fails the CPU suite."""
 import os
@@ -14,15 +14,28 @@ from tests import isa_audit
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+CSRC = os.path.join(ROOT, "reni_amd", "csrc")
+TUS = ("core", "main_f32", "main_bf16", "film_f32", "film_bf16")
+_ISA = {}
+
+
+def _isa(tu):
+    """gfx950 assembly of one translation unit, with build.sh's flags (all five are compiled in parallel once)."""
+    if not _ISA:
+        with tempfile.TemporaryDirectory() as d:
+            procs = [subprocess.Popen(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                                       "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-I" + os.path.join(ROOT, "include"),
+                                       "-I" + CSRC, os.path.join(CSRC, f"reni_tu_{t}.hip"), "-o", os.path.join(d, t + ".s")],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE) for t in TUS]
+            for t, pr in zip(TUS, procs):
+                _, err = pr.communicate()
+                assert pr.returncode == 0, err.decode()[-2000:]
+                _ISA[t] = open(os.path.join(d, t + ".s")).read()
+    return _ISA[tu]
+
+
 def test_training_kernel_agprs_only_in_hand_written_asm():
-    src = os.path.join(ROOT, "reni_amd", "csrc", "reni_kernels.hip")
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "k.s")
-        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                        "-DRENI_ONLY_TRAIN", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
-                        "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), src, "-o", out],
-                       check=True, capture_output=True)
-        text = open(out).read()
+    text = _isa("core")
     fn = [x for x in re.split(r"\n\s*\.globl\s+", text) if x.startswith("_ZN4reni17k_reni_train_bf16")]
     assert len(fn) == 1
     in_asm, touching, outside, scratch, mfma = False, 0, 0, 0, 0
@@ -50,17 +63,12 @@ def test_mfma_results_are_never_read_before_their_write_back():
     """Every MFMA of every kernel: strict wait-state count (taken branches count 0) to the first
     non-chained access of its result reaches the XDL write-back latency.  Guards against the hipcc
     hazard-padding defect that produced nondeterministic H = 256 head gradients (tests/isa_audit.py)."""
-    src = os.path.join(ROOT, "reni_amd", "csrc", "reni_kernels.hip")
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "all.s")
-        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                        "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
-                        "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), src, "-o", out],
-                       check=True, capture_output=True)
-        text = open(out).read()
-    res = isa_audit.audit(text)
-    kernels = {f for f, _ in res}
+    kernels, bad = set(), []
+    for t in TUS:  # per translation unit: local labels (.LBBn_m) repeat across units
+        text = _isa(t)
+        kernels |= {f for f, _ in isa_audit.audit(text)}
+        bad += isa_audit.violations(text)
     assert any("k_reni_train_bf16" in f for f in kernels) and any("k_reni_main" in f for f in kernels)
-    bad = isa_audit.violations(text)
+    assert sum("k_reni_main" in f for f in kernels) >= 40  # 2 precisions x 4 widths x 3 modes x {concat, FiLM}, minus MFMA-free ones
     assert not bad, "MFMA result accessed too early: " + "; ".join(
         f"{f[:48]} {k} {st} states (asm lines {a}->{b})" for f, k, st, a, b in bad[:8])

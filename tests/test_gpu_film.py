@@ -1,0 +1,165 @@
+"""GPU parity tests of the FiLM-conditioned variants (pytest -m gpu): module API -> per-image torch glue ->
+reni_film_* (C ABI) against the goldens generated from the reference (tests/golden/g11_film_*.npz) and the
+CPU oracle.  Tolerances as for the Cond-by-Concat family (tests/test_gpu_parity.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reni_oracle as O
+from tests.util import load_golden, sd_from
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": dict(out=1e-5, loss=2e-6, grad=2e-5), "bf16": dict(out=5e-3, loss=2e-3, grad=3e-2)}
+ACT = {0: None, 1: "tanh", 2: "exp"}
+EQ = {1: "SO2", 2: "SO3"}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _model_from_golden(g, dev, dtype="f32", fixed=False):
+    from reni_amd.film import RENIAutoDecoderFiLM, RENIVariationalAutoDecoderFiLM
+    eq, nd, H, nF, mf, ml, act = [int(x) for x in g["cfg"]]
+    vad = "sd.mu" in g
+    cls = RENIVariationalAutoDecoderFiLM if vad else RENIAutoDecoderFiLM
+    m = cls(2, nd, EQ[eq], H, nF, mf, ml, 3, ACT[act], fixed)
+    m.load_state_dict({"model." + k: v for k, v in sd_from(g).items()})
+    m.set_compute_dtype(dtype)
+    return m.to(dev), O.FilmSpec(nd, EQ[eq], H, nF, mf, ml, 3, ACT[act])
+
+
+def _grads(m):
+    return {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None and k not in ("Z", "mu", "log_var")}
+
+
+@pytest.mark.parametrize("tag", ["so2_ad", "so3_vad", "so2_one"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_film_golden_fused_training_step(dev, tag, dtype):
+    """fused forward + RENITrainLoss + backward: out, loss, dZ and the gradient of EVERY parameter (SIREN, head,
+    mapping network) against the reference's autograd."""
+    g = load_golden(f"g11_film_{tag}.npz")
+    m, spec = _model_from_golden(g, dev, dtype)
+    W = int(g["W"])
+    D = O.get_directions(W).to(dev)
+    S = O.get_sineweight(W).to(dev)
+    T = torch.from_numpy(g["target"]).to(dev)
+    Z = torch.from_numpy(g["Z"]).to(dev).requires_grad_(True)
+    tol = TOL[dtype]
+    with torch.no_grad():
+        out = m(Z.detach(), D)
+    assert float((out.cpu() - torch.from_numpy(g["out"])).abs().max()) <= tol["out"]
+    terms = m.fused_loss(Z, D, T, S)
+    terms[0].backward()
+    assert abs(float(terms[0]) - float(g["loss"])) <= tol["loss"] * abs(float(g["loss"]))
+    assert O.rel_l2(Z.grad.cpu().numpy(), g["dZ"]) <= tol["grad"]
+    got = _grads(m)
+    want = {k[2:]: v for k, v in g.items() if k.startswith("g.")}
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert O.rel_l2(got[k].numpy(), want[k]) <= tol["grad"], k
+
+
+@pytest.mark.parametrize("tag", ["so2_ad", "so3_vad"])
+def test_film_golden_generic_autograd_and_test_loss(dev, tag):
+    """model(Z, D) followed by a torch-side loss (reni_film_backward) and the fused RENITestLoss path, fp32."""
+    from reni_amd.loss_functions import RENITestLoss, RENITrainLoss
+    g = load_golden(f"g11_film_{tag}.npz")
+    m, spec = _model_from_golden(g, dev)
+    W = int(g["W"])
+    D = O.get_directions(W).to(dev).repeat(2, 1, 1)
+    S = O.get_sineweight(W).to(dev).repeat(2, 1, 1)
+    T = torch.from_numpy(g["target"]).to(dev)
+    Z = torch.from_numpy(g["Z"]).to(dev).requires_grad_(True)
+    loss = RENITrainLoss()(m(Z, D), T, S)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    assert O.rel_l2(Z.grad.cpu().numpy(), g["dZ"]) <= 2e-5
+    got = _grads(m)
+    for k, v in g.items():
+        if k.startswith("g."):
+            assert O.rel_l2(got[k[2:]].numpy(), v) <= 2e-5, k
+    # RENITestLoss(alpha, beta): (loss, mse, prior, cosine) and the latent gradient
+    Z2 = torch.from_numpy(g["Z"]).to(dev).requires_grad_(True)
+    t_fused = m.fused_loss(Z2, D, T, S, loss_kind="test", alpha=1e-3, beta=1e-1)
+    t_fused[0].backward()
+    assert np.abs(t_fused.detach().cpu().numpy() - g["test_terms"]).max() <= 2e-6 * abs(g["test_terms"][0])
+    assert O.rel_l2(Z2.grad.cpu().numpy(), g["test_dZ"]) <= 2e-5
+    Z3 = torch.from_numpy(g["Z"]).to(dev).requires_grad_(True)
+    t_torch = RENITestLoss(alpha=1e-3, beta=1e-1)(m(Z3, D), T, S, Z3)
+    t_torch[0].backward()
+    assert O.rel_l2(Z3.grad.cpu().numpy(), g["test_dZ"]) <= 2e-5
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [
+    dict(eq="SO2", nd=5, H=32, nF=2, P=77, B=3),
+    dict(eq="SO3", nd=9, H=64, nF=4, P=333, B=2),
+    dict(eq="SO2", nd=9, H=128, nF=3, P=200, B=2),
+    dict(eq="SO2", nd=36, H=128, nF=5, P=128, B=1),
+    dict(eq="SO3", nd=9, H=256, nF=3, P=150, B=2),
+], ids=lambda c: f"{c['eq']}-nd{c['nd']}-H{c['H']}-nF{c['nF']}")
+def test_film_random_problems_vs_oracle(dev, cfg, dtype):
+    """every compiled width, ragged tiles, per-image direction sets, frozen and trainable decoders"""
+    from reni_amd.film import RENIAutoDecoderFiLM
+    spec = O.FilmSpec(cfg["nd"], cfg["eq"], cfg["H"], cfg["nF"], 24, 2, 3, "tanh")
+    gen = torch.Generator().manual_seed(5)
+    params = O.film_init_params(spec, gen)
+    B, P = cfg["B"], cfg["P"]
+    Z = torch.randn(B, cfg["nd"], 3, generator=gen) * 0.5
+    D = torch.nn.functional.normalize(torch.randn(B, P, 3, generator=gen), dim=-1)
+    S = torch.rand(1, P, 3, generator=gen)
+    T = torch.rand(B, P, 3, generator=gen) * 2 - 1
+    ref = O.film_fwd_loss_bwd(spec, params, Z, D, T, S)
+    tol = TOL[dtype]
+    for fixed in (False, True):
+        m = RENIAutoDecoderFiLM(B, cfg["nd"], cfg["eq"], cfg["H"], cfg["nF"], 24, 2, 3, "tanh", fixed)
+        m.load_state_dict({"model." + k: v for k, v in params.items()}, strict=False)
+        m.set_compute_dtype(dtype).to(dev)
+        Zd = Z.to(dev).requires_grad_(True)
+        terms = m.fused_loss(Zd, D.to(dev), T.to(dev), S.to(dev))
+        terms[0].backward()
+        assert abs(float(terms[0]) - ref["terms"][0]) <= tol["loss"] * abs(ref["terms"][0])
+        assert O.rel_l2(Zd.grad.cpu().numpy(), ref["dZ"].numpy()) <= tol["grad"], ("dZ", fixed)
+        got = _grads(m)
+        if fixed:
+            assert not got  # frozen decoder: only the latent receives a gradient
+        else:
+            for k, v in ref["grads"].items():
+                assert O.rel_l2(got[k].numpy(), v.numpy()) <= tol["grad"], k
+
+
+def test_film_full_size_properties(dev):
+    """BASELINE-sized FiLM problem (128x256 grid, ND = 36, 5 x 128): additivity of the loss and of every gradient
+    over a split of the batch, bf16 vs fp32 agreement, run-to-run determinism."""
+    from reni_amd.film import RENIAutoDecoderFiLM
+    torch.manual_seed(3)
+    m = RENIAutoDecoderFiLM(4, 36, "SO2", 128, 5, 128, 3, 3, "tanh", False).to(dev)
+    D = O.get_directions(256).to(dev)
+    S = O.get_sineweight(256).to(dev)
+    T = (torch.rand(4, D.shape[1], 3, generator=torch.Generator().manual_seed(9)) * 2 - 1).to(dev)
+    idx = torch.arange(4, device=dev)
+
+    def step(sel, dtype):
+        m.set_compute_dtype(dtype)
+        m.zero_grad(set_to_none=True)
+        terms = m.fused_loss(m.Z[sel], D, T[sel], S)
+        terms[0].backward()
+        flat = torch.cat([p.grad.reshape(-1) for k, p in m.named_parameters() if k != "Z"])
+        return float(terms[0]), flat.clone(), m.Z.grad.clone()
+
+    la, ga, za = step(idx, "f32")
+    lb, gb, zb = step(idx, "f32")
+    assert la == lb and torch.equal(ga, gb) and torch.equal(za, zb)
+    l0, g0, z0 = step(idx[:2], "f32")
+    l1, g1, z1 = step(idx[2:], "f32")
+    assert abs(l0 + l1 - la) <= 2e-6 * abs(la)
+    assert O.rel_l2((g0 + g1).cpu().numpy(), ga.cpu().numpy()) <= 2e-5
+    assert O.rel_l2((z0 + z1).cpu().numpy(), za.cpu().numpy()) <= 2e-5
+    lh, gh, zh = step(idx, "bf16")
+    assert abs(lh - la) <= 2e-3 * abs(la)
+    assert O.rel_l2(gh.cpu().numpy(), ga.cpu().numpy()) <= 3e-2
+    assert O.rel_l2(zh.cpu().numpy(), za.cpu().numpy()) <= 3e-2

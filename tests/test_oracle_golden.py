@@ -154,3 +154,32 @@ def test_g10_invariance_identities(golden):
         np.testing.assert_allclose(a[0, :128].numpy(), g[f"out_{eq}_head"], atol=3e-6)
         assert float((a - b).abs().max()) < 5e-6
         assert float(g[f"resid_{eq}"]) < 5e-6
+
+
+# ---- G11: FiLM conditioning ---------------------------------------------------------
+@pytest.mark.parametrize("tag", ["so2_ad", "so3_vad", "so2_one"])
+def test_g11_film_oracle_matches_reference(golden, tag):
+    """film_encode / film_mapping / film_forward / film_fwd_loss_bwd against the reference's RENI*FiLM modules
+    (forward, RENITrainLoss gradients of every parameter and of Z, RENITestLoss terms and latent gradient)."""
+    g = golden(f"g11_film_{tag}.npz")
+    eq, nd, H, nF, mf, ml, act = [int(x) for x in g["cfg"]]
+    spec = O.FilmSpec(nd, {1: "SO2", 2: "SO3"}[eq], H, nF, mf, ml, 3, {0: None, 1: "tanh", 2: "exp"}[act])
+    params = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.") and k[3:] not in ("Z", "mu", "log_var")}
+    assert sorted(params) == sorted(spec.param_keys())
+    W = int(g["W"])
+    D = O.get_directions(W).repeat(2, 1, 1)
+    S = O.get_sineweight(W).repeat(2, 1, 1)
+    Z, T = torch.from_numpy(g["Z"]), torch.from_numpy(g["target"])
+    si, mi = O.film_encode(spec, Z, D)
+    assert np.abs(si[:, :8].numpy() - g["siren_input_head"]).max() <= 1e-6
+    f, ph = O.film_mapping(spec, params, mi)
+    assert np.abs(f.numpy() - g["freq_raw"]).max() <= 2e-6 and np.abs(ph.numpy() - g["phase"]).max() <= 2e-6
+    r = O.film_fwd_loss_bwd(spec, params, Z, D, T, S)
+    assert np.abs(r["out"].numpy() - g["out"]).max() <= 1e-6
+    assert abs(r["terms"][0] - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+    assert O.rel_l2(r["dZ"].numpy(), g["dZ"]) <= 5e-6
+    for k in params:
+        assert O.rel_l2(r["grads"][k].numpy(), g["g." + k]) <= 5e-6, k
+    r2 = O.film_fwd_loss_bwd(spec, params, Z, D, T, S, "test", 1e-3, 1e-1)
+    assert np.abs(np.array(r2["terms"]) - g["test_terms"]).max() <= 1e-6 * abs(g["test_terms"][0])
+    assert O.rel_l2(r2["dZ"].numpy(), g["test_dZ"]) <= 5e-6
