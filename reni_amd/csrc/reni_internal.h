@@ -1,4 +1,4 @@
-// reni_internal.h -- kernel argument blocks shared by reni_kernels.hip and reni_capi.inc
+// reni_internal.h -- kernel argument blocks shared by reni_device.inc (the reni_tu_*.hip translation units) and reni_capi.inc
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
