@@ -71,6 +71,7 @@ struct PackDesc {
   int transposed;     // 0: image rows = M rows, k = K cols ; 1: image rows = K cols, k = M rows
   int nrb, nks;       // image geometry
   int bias_n, bias_n_pad;
+  float scale;        // every weight and bias of the image is multiplied by this (1 = plain copy)
 };
 
 struct PackArgs {
