@@ -101,6 +101,59 @@ def audit(text, taken_branch_states=0):
     return res
 
 
+def valu_to_mfma(text, need=2):
+    """VALU write of a VGPR -> MFMA reading it as SrcA/SrcB/SrcC needs `need` wait states.  hipcc pads its own MFMAs;
+    an asm MFMA without a leading s_nop relies on nothing of the kind sitting in front of it, which is what this
+    checks: -> [(function, line of the VALU, line of the MFMA, states between)] for every violation, following
+    fall-through and branch predecessors."""
+    labels, prog, fnames = parse(text)
+    fk = sorted(fnames)
+
+    def fn(k):
+        j = bisect.bisect_right(fk, k) - 1
+        return fnames[fk[j]] if j >= 0 else "?"
+
+    label_at = collections.defaultdict(list)
+    for name, pc in labels.items():
+        label_at[pc].append(name)
+    preds = collections.defaultdict(list)  # pc -> [pc of branches that jump here]
+    for pc, (_, t) in enumerate(prog):
+        op = t.split()[0]
+        if op == "s_branch" or op.startswith("s_cbranch"):
+            tgt = t.split()[1]
+            if tgt in labels:
+                preds[labels[tgt]].append(pc)
+    bad = []
+    for k, (ln, t) in enumerate(prog):
+        if not t.startswith("v_mfma"):
+            continue
+        ops = t.split(None, 1)[1].split(",")
+        src = _regs(ops[1]) | _regs(ops[2]) | {r for r in _regs(ops[3]) if r[0] == "v"}
+        src = {r for r in src if r[0] == "v"}
+        stack, seen = [(k - 1, 0)], set()
+        while stack:
+            pc, st = stack.pop()
+            while pc >= 0 and st < need:
+                if (pc, st) in seen:
+                    break
+                seen.add((pc, st))
+                for b in preds.get(pc + 1, ()):  # instruction pc+1 is a branch target: also come from the branch
+                    if b != pc:
+                        stack.append((b, st))
+                l2, t2 = prog[pc]
+                op = t2.split()[0]
+                if op == "s_branch":  # no fall-through into pc+1 from here
+                    break
+                if op.startswith("v_") and not op.startswith(("v_mfma", "v_cmp", "v_readlane", "v_readfirstlane")):
+                    dst = _regs(t2.split(None, 1)[1].split(",")[0]) if " " in t2 else set()
+                    if dst & src:
+                        bad.append((fn(k), l2, ln, st))
+                        break
+                st += _states(t2)
+                pc -= 1
+    return bad
+
+
 def violations(text, skip=("k_probe",)):
     bad = []
     for (f, kind), v in audit(text).items():
@@ -116,3 +169,5 @@ if __name__ == "__main__":
         print(f[:70].ljust(70), kind[7:], "min states", min(x[0] for x in v), "accesses", len(v))
     for b in violations(txt):
         print("VIOLATION", b)
+    for b in valu_to_mfma(txt):
+        print("VALU->MFMA", b)

@@ -68,6 +68,9 @@ def test_mfma_results_are_never_read_before_their_write_back():
         text = _isa(t)
         kernels |= {f for f, _ in isa_audit.audit(text)}
         bad += isa_audit.violations(text)
+        early = isa_audit.valu_to_mfma(text)
+        assert not early, f"VALU write within 2 wait states of an MFMA reading it ({t}): " + "; ".join(
+            f"{f[:40]} asm lines {a}->{b} ({st} states)" for f, a, b, st in early[:8])
     assert any("k_reni_train_bf16" in f for f in kernels) and any("k_reni_main" in f for f in kernels)
     assert sum("k_reni_main" in f for f in kernels) >= 40  # 2 precisions x 4 widths x 3 modes x {concat, FiLM}, minus MFMA-free ones
     assert not bad, "MFMA result accessed too early: " + "; ".join(
