@@ -36,7 +36,7 @@ struct MainArgs {
   size_t dwp_per_wg;
   unsigned p_off_w[MAX_LAYERS + 2];  // float offsets of W_l / b_l in the flat layout
   unsigned p_off_b[MAX_LAYERS + 2];
-  float* dA_part;    // [n_tiles][H][16]
+  float* dA_part;    // [n_tiles][H][8]: columns dx, dy, dz, r, 1 (hi + lo parts summed), 3 unused
   float* loss_part;  // [n_tiles][4][16]
   char* g1;          // [n_tiles][H/16][256][16 B] bf16 g_1 stream (persistent training path)
   long long* trace;  // optional (tag, s_memtime) pairs from workgroup 0 (RENI_TRACE builds)
