@@ -361,8 +361,29 @@ def g11():
              cfg=np.array([{"SO2": 1, "SO3": 2}[eq], 9, H, nF, mf, ml, {None: 0, "tanh": 1, "exp": 2}[act]]), **arrs)
 
 
+# ---------------------------------------------------------------- G12 HDR transforms
+def g12():
+    """MinMaxNormalise / UnMinMaxNormlise / UnNormalise (src/utils/custom_transforms.py) and sRGB (src/utils/utils.py:30-42)
+    on a synthetic HDR image with zeros, an inf and a large dynamic range."""
+    from src.utils import custom_transforms as ref_ct
+    g = torch.Generator().manual_seed(12)
+    img = torch.exp(torch.randn(3, 16, 32, generator=g) * 2.0 - 3.0)
+    img[0, 0, 0] = 0.0
+    img[1, 3, 4] = float("inf")
+    img[2, 5, 6] = 1e4
+    minmax = [-18.0536, 11.4633]  # configs/experiment.yaml:88
+    n = ref_ct.MinMaxNormalise(minmax)(img.clone())
+    u = ref_ct.UnMinMaxNormlise(minmax)(n.clone())
+    batch = torch.rand(2, 3, 4, 5, generator=g)
+    un = ref_ct.UnNormalise([0.1, 0.2, 0.3], [1.5, 2.5, 3.5])(batch.clone())
+    srgb1 = ref_utils.sRGB(u.clone())
+    srgb2 = ref_utils.sRGB(torch.rand(2, 3, 8, 16, generator=torch.Generator().manual_seed(13)) * 3.0)
+    save("g12_transforms.npz", img=img.numpy(), minmax=np.array(minmax), normalised=n.numpy(), unnormalised=u.numpy(),
+         batch=batch.numpy(), unnorm_batch=un.numpy(), srgb1=srgb1.numpy(), srgb2=srgb2.numpy())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for w in which:
         globals()[w]()

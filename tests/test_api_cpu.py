@@ -213,3 +213,23 @@ def test_get_mask(tmp_path, golden):
     assert m.shape == (1, 32 * 64, 3)
     assert np.array_equal(m.numpy(), g["mask"])
     assert abs(float(m.mean()) - 0.188) < 0.01  # Mask-3 keeps ~18.8 % of the pixels
+
+
+def test_hdr_transforms_match_reference(golden):
+    """MinMaxNormalise / UnMinMaxNormlise / UnNormalise / sRGB against the reference's outputs (G12)."""
+    from reni_amd.custom_transforms import MinMaxNormalise, UnMinMaxNormlise, UnNormalise, transform_builder
+    g = golden("g12_transforms.npz")
+    img = torch.from_numpy(g["img"])
+    minmax = [float(g["minmax"][0]), float(g["minmax"][1])]
+    n = MinMaxNormalise(minmax)(img.clone())
+    assert np.array_equal(n.numpy(), g["normalised"])
+    assert np.array_equal(transform_builder([("minmaxnormalise", minmax)])(img.clone()).numpy(), g["normalised"])
+    u = UnMinMaxNormlise(minmax)(n.clone())
+    assert np.array_equal(u.numpy(), g["unnormalised"])
+    un = UnNormalise([0.1, 0.2, 0.3], [1.5, 2.5, 3.5])(torch.from_numpy(g["batch"]).clone())
+    assert np.array_equal(un.numpy(), g["unnorm_batch"])
+    np.testing.assert_allclose(utils.sRGB(u.clone()).numpy(), g["srgb1"], rtol=0, atol=1e-6)
+    x2 = torch.rand(2, 3, 8, 16, generator=torch.Generator().manual_seed(13)) * 3.0
+    np.testing.assert_allclose(utils.sRGB(x2).numpy(), g["srgb2"], rtol=0, atol=1e-6)
+    with pytest.raises(NotImplementedError, match="torchvision"):
+        transform_builder([("resize", [64, 128])])
