@@ -46,6 +46,11 @@ struct MainArgs {
   float* dfp_part;      // [n_tiles][L][2][H] per-tile d(freq), d(phase)
   const float* params;  // flat fp32 parameters (d(freq) needs W_l and b_l)
   unsigned n_first;     // p_off_* are relative to the partial buffer: params offset = p_off + n_first
+  // wide bf16 training (H = 256): a layer's 256 x 256 weight gradient does not fit a workgroup's registers next to
+  // the chain, so k_reni_main writes the transposed operand images of every (layer, tile, 64-sample round) to this
+  // stream and k_dw_stream256 finishes dW_l with one layer's accumulator resident in its AGPRs.
+  // [L][n_tiles][2 rounds][2 images (g_l | h_{l-1})][256 features][T_ROWB bytes]
+  char* dws;
 };
 
 // host launchers of the fused kernel, one per translation unit (reni_device.inc)
