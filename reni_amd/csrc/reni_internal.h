@@ -51,6 +51,11 @@ struct MainArgs {
   // stream and k_dw_stream256 finishes dW_l with one layer's accumulator resident in its AGPRs.
   // [L][n_tiles][2 rounds][2 images (g_l | h_{l-1})][256 features][T_ROWB bytes]
   char* dws;
+  // FiLM on the stream path: a workgroup's contiguous record range is cut into per-image runs; run k of workgroup w
+  // writes dfr[((w * kmax + k) * L + l-1)][2][H] = (sum_k W (.) M rows, d(phase)) and run_image[w * kmax + k] = image
+  float* dfr;
+  int* run_image;
+  int kmax;
 };
 
 // host launchers of the fused kernel, one per translation unit (reni_device.inc)
