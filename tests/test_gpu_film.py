@@ -163,3 +163,30 @@ def test_film_full_size_properties(dev):
     assert abs(lh - la) <= 2e-3 * abs(la)
     assert O.rel_l2(gh.cpu().numpy(), ga.cpu().numpy()) <= 3e-2
     assert O.rel_l2(zh.cpu().numpy(), za.cpu().numpy()) <= 3e-2
+
+
+@pytest.mark.parametrize("H,nF", [(128, 3), (256, 2)])
+def test_film_stream_runs_many_small_images(dev, H, nF):
+    """Stream path bookkeeping: more one-tile images than workgroups, so a workgroup's record range covers several
+    images (several runs per workgroup) -- gradients of every parameter and of every latent against the oracle."""
+    from reni_amd.film import RENIAutoDecoderFiLM
+    B, P, nd = 700, 96, 4
+    spec = O.FilmSpec(nd, "SO2", H, nF, 16, 1, 3, "tanh")
+    gen = torch.Generator().manual_seed(11)
+    params = O.film_init_params(spec, gen)
+    Z = torch.randn(B, nd, 3, generator=gen) * 0.5
+    D = torch.nn.functional.normalize(torch.randn(1, P, 3, generator=gen), dim=-1)
+    S = torch.rand(1, P, 3, generator=gen)
+    T = torch.rand(B, P, 3, generator=gen) * 2 - 1
+    ref = O.film_fwd_loss_bwd(spec, params, Z, D, T, S)
+    m = RENIAutoDecoderFiLM(B, nd, "SO2", H, nF, 16, 1, 3, "tanh", False)
+    m.load_state_dict({"model." + k: v for k, v in params.items()}, strict=False)
+    m.set_compute_dtype("bf16").to(dev)
+    Zd = Z.to(dev).requires_grad_(True)
+    terms = m.fused_loss(Zd, D.to(dev), T.to(dev), S.to(dev))
+    terms[0].backward()
+    assert abs(float(terms[0].detach()) - ref["terms"][0]) <= 2e-3 * abs(ref["terms"][0])
+    assert O.rel_l2(Zd.grad.cpu().numpy(), ref["dZ"].numpy()) <= 3e-2
+    got = _grads(m)
+    for k, v in ref["grads"].items():
+        assert O.rel_l2(got[k].numpy(), v.numpy()) <= 3e-2, k

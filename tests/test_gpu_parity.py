@@ -210,3 +210,16 @@ def test_fused_adam_matches_torch(dev):
         pa.grad = g.clone(); pb.grad = g.clone()
         oa.step(); ob.step()
     assert float((pa - pb).abs().max()) <= 1e-6
+
+
+def test_wide_stream_path_more_tiles_than_workgroups(dev):
+    """H = 256 bf16 (operand stream + k_dw_stream): 300 one-tile images on 256 CUs -- contiguous record ranges of
+    unequal length, ragged tiles -- every gradient against the oracle, and run-to-run bit-equality."""
+    spec = O.DecoderSpec(4, "SO3", 256, 2, 3, True, "tanh")
+    params, Z, D, W, T = random_problem(spec, 300, 100, seed=21)
+    plan = make_plan(spec, "bf16")
+    _check(plan, spec, params, Z, D, W, T, dev, "bf16")
+    fp = flat_params(spec, params).to(dev)
+    a = plan.forward_loss_backward(Z.to(dev), D.to(dev), fp, T.to(dev), W.to(dev))
+    b = plan.forward_loss_backward(Z.to(dev), D.to(dev), fp, T.to(dev), W.to(dev))
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
