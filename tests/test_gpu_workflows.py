@@ -205,3 +205,40 @@ def test_c2_full_size_additivity(dev, dtype):
     ref = O.reni_forward(spec, params, Z, D[:, sl].expand(3, -1, 3))
     tol = 1e-5 if dtype == "f32" else 5e-3
     assert float((out[:, sl].cpu() - ref).abs().max()) <= tol
+
+
+def test_multires_curriculum_and_exponential_lr(dev):
+    """MultiResTrainingCallback semantics (callbacks.py:11-29) and the per-epoch ExponentialLR
+    (RENI_module.py:213-214, 243-251) through the fit loop: the grids, the dataset and the kernels' problem size
+    double at the curriculum epochs; the learning rate follows lr_start * gamma^epoch with
+    gamma = exp(ln(lr_end / lr_start) / epochs); the FiLM model trains through the same loop."""
+    from reni_amd import trainer
+    from reni_amd.lightning_module import RENI
+    for conditioning in ("Cond-by-Concat", "FiLM"):
+        cfg = _config(LR_START=1e-2, LR_END=1e-4, SCHEDULER_TYPE="exponential", EPOCHS=4, BATCH_SIZE=2,
+                      MULTI_RES_TRAINING=True, INITAL_RESOLUTION=[8, 16], FINAL_RESOLUTION=[32, 64], CURRICULUM=[1, 3])
+        cfg.RENI.CONDITIONING = conditioning
+        cfg.DATASET = types.SimpleNamespace(NAME="SYNTHETIC", SYNTHETIC=types.SimpleNamespace(N_TRAIN=4, N_TEST=2))
+        torch.manual_seed(0)
+        mod = RENI(cfg, "FIT_DECODER")
+        seen = []
+        orig = mod.training_step
+
+        def spy(batch, bi, orig=orig, mod=mod, seen=seen):
+            seen.append((mod.current_epoch, tuple(batch[0].shape[-2:]), mod.directions.shape[1]))
+            return orig(batch, bi)
+
+        mod.training_step = spy
+        hist = trainer.fit(mod, max_epochs=4, device=dev)
+        res = {e: (hw, p) for e, hw, p in seen}
+        assert res[0] == ((8, 16), 128) and res[1] == ((16, 32), 512) and res[2] == ((16, 32), 512) and res[3] == ((32, 64), 2048)
+        assert mod.cur_res == [32, 64] and len(hist) == 4 and all(np.isfinite(h["loss"]) for h in hist)
+        opt = mod.configure_optimizers  # a fresh optimiser + scheduler pair to read the schedule
+        pair = opt()
+        sched, o = pair["lr_scheduler"]["scheduler"], pair["optimizer"]
+        gamma = np.exp(np.log(1e-4 / 1e-2) / 4)
+        lrs = []
+        for _ in range(4):
+            lrs.append(o.param_groups[0]["lr"])
+            sched.step()
+        np.testing.assert_allclose(lrs, [1e-2 * gamma ** e for e in range(4)], rtol=1e-6)
