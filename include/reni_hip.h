@@ -92,7 +92,10 @@ int64_t reni_param_count(const reni_plan* plan);
 int32_t reni_in_features(const reni_plan* plan);
 
 /* Bytes of workspace the calls below need for (B images) x (P directions).  `flags` as passed
- * to the call (0 for reni_forward). */
+ * to the call (0 for reni_forward).  Rule of thumb per 128 directions (one tile): 8 KB of partials; plus, for the
+ * backward entry points, 32 KB (bf16, H = 128 persistent path: the g_1 stream) or hidden_layers x 70 KB (FiLM, H = 128)
+ * / x 144 KB (H = 256) of operand stream on the bf16 stream path (k_dw_stream) -- e.g. 64 images x 32768 directions:
+ * 0.8 GB, 5.7 GB, 12 GB.  The stash ring and the per-workgroup gradient partials do not grow with B x P. */
 size_t reni_workspace_bytes(const reni_plan* plan, int64_t B, int64_t P, uint32_t flags);
 
 /* out[B,P,3] = model(Z, D) under no_grad -- replaces InvariantRepresentation + self.net(x)
