@@ -77,6 +77,9 @@ typedef struct reni_desc {
   int32_t dtype;             /* RENI_F32 | RENI_BF16 */
   int32_t conditioning;      /* RENI_COND_*.  FiLM: hidden_layers = siren_hidden_layers - 1 (RENI.py:563-568),
                                 omegas unused, last_layer_linear = 1                     RENI.py:537-570 */
+  int32_t mapping_layers;    /* FiLM: hidden layers of the mapping network (0 = the reni_film_model_* entry points are
+                                not used)                                                RENI.py:482-496 */
+  int32_t mapping_features;  /* FiLM: width of those layers                             RENI.py:482-496 */
 } reni_desc;
 
 /* Message of the last error raised on this thread ("" if none). */
@@ -158,6 +161,28 @@ int reni_film_backward(const reni_plan* plan, int64_t B, int64_t P, const float*
                        const float* A, const float* film, const float* params, const float* dout,
                        uint32_t flags, float* dA, float* dfilm, float* dparams, void* ws, size_t ws_bytes,
                        void* stream);
+
+/* FiLM, whole model: the per-image glue of the three calls above runs in HIP too (k_film_map_fwd / _bwd,
+ * k_film_wgrad, k_film_w0grad), so these take the latent codes and the mapping network's parameters and return
+ * their gradients -- the drop-in for RENI*FiLM.forward (RENI.py:628-676) + criterion + loss.backward().
+ *   map_params / dmap_params : mapping_network.network.{0,2,...}.{weight [N_i,K_i], bias [N_i]} flat, in state-dict
+ *                              order (RENI.py:482-496); reni_film_map_param_count() elements;
+ *   dparams                  : flat net.* / final_layer.* gradient INCLUDING the first layer's slot;
+ *   loss_terms               : (loss, mse, prior, cosine) with prior = alpha |Z|^2 (RENI_LOSS_TEST). */
+int64_t reni_film_map_param_count(const reni_plan* plan);
+int reni_film_model_forward(const reni_plan* plan, int64_t B, int64_t P, const float* Z, const float* D,
+                            int64_t d_batch_stride, const float* params, const float* map_params, float* out,
+                            void* ws, size_t ws_bytes, void* stream);
+int reni_film_model_forward_loss_backward(const reni_plan* plan, int64_t B, int64_t P, const float* Z, const float* D,
+                                          int64_t d_batch_stride, const float* params, const float* map_params,
+                                          const float* target, const int64_t tgt_strides[3], const float* weight,
+                                          const int64_t w_strides[3], int32_t loss_kind, float alpha, float beta,
+                                          uint32_t flags, float* out, float* loss_terms, float* dZ, float* dparams,
+                                          float* dmap_params, void* ws, size_t ws_bytes, void* stream);
+int reni_film_model_backward(const reni_plan* plan, int64_t B, int64_t P, const float* Z, const float* D,
+                             int64_t d_batch_stride, const float* params, const float* map_params, const float* dout,
+                             uint32_t flags, float* dZ, float* dparams, float* dmap_params, void* ws, size_t ws_bytes,
+                             void* stream);
 
 /* torch.optim.Adam(lr, betas=(b1,b2), eps) step on a flat buffer (RENI_module.py:192: the
  * reference always uses the default betas (0.9, 0.999), eps 1e-8).  `step` is the 1-based step

@@ -27,6 +27,8 @@ EXPORTS = (
     "reni_workspace_bytes", "reni_forward", "reni_forward_loss_backward", "reni_backward",
     "reni_adam_step", "reni_selftest_layouts", "reni_launch_info", "reni_profile_enable", "reni_profile_read", "reni_probe_tr",
     "reni_film_forward", "reni_film_forward_loss_backward", "reni_film_backward",
+    "reni_film_map_param_count", "reni_film_model_forward", "reni_film_model_forward_loss_backward",
+    "reni_film_model_backward",
 )
 
 
@@ -35,7 +37,7 @@ class reni_desc(Structure):
         ("equivariance", c_int32), ("ndims", c_int32), ("hidden_features", c_int32),
         ("hidden_layers", c_int32), ("out_features", c_int32), ("last_layer_linear", c_int32),
         ("output_activation", c_int32), ("first_omega_0", c_float), ("hidden_omega_0", c_float),
-        ("dtype", c_int32), ("conditioning", c_int32),
+        ("dtype", c_int32), ("conditioning", c_int32), ("mapping_layers", c_int32), ("mapping_features", c_int32),
     ]
 
 
@@ -90,6 +92,18 @@ def load():
     lib.reni_film_backward.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.reni_film_backward.restype = c_int32
+    lib.reni_film_map_param_count.argtypes = [c_void_p]
+    lib.reni_film_map_param_count.restype = c_int64
+    lib.reni_film_model_forward.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.reni_film_model_forward.restype = c_int32
+    lib.reni_film_model_forward_loss_backward.argtypes = [
+        c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, i64x3, c_void_p, i64x3,
+        c_int32, c_float, c_float, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.reni_film_model_forward_loss_backward.restype = c_int32
+    lib.reni_film_model_backward.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                             c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.reni_film_model_backward.restype = c_int32
     lib.reni_adam_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                    c_float, c_int64, c_float, c_void_p]
     lib.reni_adam_step.restype = c_int32

@@ -104,4 +104,27 @@ struct TailArgs {
   int eq, nd, F_in, H, B;
 };
 
+// FiLM per-image glue (k_film_map_fwd / k_film_map_bwd / k_film_wgrad / k_film_w0grad): the mapping network
+// (src/models/RENI.py:482-505), freq = 15 f + 30, and the first FiLM layer folded into the per-image affine map
+constexpr int MAX_MAP_LAYERS = 8;
+struct FilmGlueArgs {
+  const float* Z;        // [B][nd][3]
+  const float* params;   // flat net.* / final_layer.* (net.0 = W0 [H][F0], b0 [H] first)
+  const float* mparams;  // flat mapping_network.network.{0,2,..}.{weight,bias}
+  float* A;              // [B][H][8]   out (forward)
+  float* film;           // [B][L][2][H] out (forward)
+  float* mapm;           // [B][M_in]      saved mapping input
+  float* mapx;           // [B][ML][Hm]    saved post-activation inputs of mapping layers 1..ML
+  float* fo;             // [B][N_out]     saved mapping output
+  const float* dA;       // [B][H][8]   in (backward)
+  const float* dfilm;    // [B][L][2][H] in (backward)
+  float* dAb;            // [B][H][8]  freq_0 . dA: gradient w.r.t. the un-modulated first-layer map
+  float* dly;            // deltas of the mapping layers' outputs, block i = [B][N_i] at dly_off[i]
+  float* dZ;             // [B][nd][3] out (backward)
+  float alpha2;          // 2 alpha of the latent prior alpha |Z|^2 (RENITestLoss), 0 otherwise
+  int eq, nd, H, L, F0, M_in, Hm, ML, N_out, B;
+  unsigned mw_off[MAX_MAP_LAYERS + 1], mb_off[MAX_MAP_LAYERS + 1];
+  unsigned dly_off[MAX_MAP_LAYERS + 1];
+};
+
 }  // namespace reni

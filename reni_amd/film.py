@@ -5,18 +5,19 @@ Same class names, constructor arguments, attributes, ``state_dict`` keys (``net.
 dispatch, ``sample_latent``, ``load_state_dict`` remapping and RNG consumption order as the reference, so a
 torch seed yields the reference's initial weights.
 
-Where the work runs:
+Where the work runs: everything in ``libreni_hip.so`` through ``reni_film_model_*`` (include/reni_hip.h) -- the
+per-SAMPLE FiLM SIREN, loss and backward in the fused kernels, and the per-IMAGE glue in small HIP kernels:
 
-* per SAMPLE (B x P rows: the FiLM SIREN, loss, backward) -- the fused HIP kernels of ``libreni_hip.so``
-  through ``reni_film_*`` (include/reni_hip.h).  No CPU fallback.
-* per IMAGE (B rows) -- differentiable torch ops on the device, below in ``_glue``:
-    - the mapping network, evaluated ONCE per image (the reference evaluates it on every pixel of rows it
-      just ``repeat``-ed, RENI.py:413-447; the values are identical);
-    - the first FiLM layer folded into a per-image affine map of the direction: its input
-      ``[|d_xz|, d_y, D_xz Z_xz^T]`` (SO2, RENI.py:441) / ``D Z^T`` (SO3, RENI.py:410) is linear in
-      ``(dx, dy, dz, r)``, hence ``freq_0 (W_0 x + b_0) + phase_0 = A_b (dx, dy, dz, r, 1)``.
-  torch autograd carries ``dA`` and ``d(freq, phase)`` returned by the kernels back through this glue to the
-  mapping network, the first layer and the latent codes.
+  - the mapping network, evaluated ONCE per image (the reference evaluates it on every pixel of rows it just
+    ``repeat``-ed, RENI.py:413-447; the values are identical), ``freq = 15 f + 30``;
+  - the first FiLM layer folded into a per-image affine map of the direction: its input
+    ``[|d_xz|, d_y, D_xz Z_xz^T]`` (SO2, RENI.py:441) / ``D Z^T`` (SO3, RENI.py:410) is linear in
+    ``(dx, dy, dz, r)``, hence ``freq_0 (W_0 x + b_0) + phase_0 = A_b (dx, dy, dz, r, 1)``;
+  - their backward: gradients of the mapping network, of the first layer and of the latent codes.
+
+No CPU fallback.  ``_glue`` below restates the per-image math in differentiable torch ops; it is what the
+``reni_film_forward`` / ``reni_film_backward`` core entry points expect from a caller that owns the glue, and the
+tests use it to check the HIP glue.
 """
 from __future__ import annotations
 
@@ -98,47 +99,47 @@ class FiLMLayer(nn.Module):
 
 
 class _FilmDecodeFn(torch.autograd.Function):
-    """out = SIREN core(A, film, D).  backward = reni_film_backward (forward recomputed in the fused kernel)."""
+    """out = model(Z, D).  backward = reni_film_model_backward (forward recomputed inside the fused kernel)."""
 
     @staticmethod
-    def forward(ctx, model, A, film, D, *params):
-        flat = model._flat_params()
-        out = model._plan().film_forward(A, film, D, flat)
-        ctx.model = model
-        ctx.n_params = len(params)
+    def forward(ctx, model, Z, D, n_net, *params):
+        flat, mflat = model._flat_params(), model._map_flat()
+        out = model._plan().film_model_forward(Z, D, flat, mflat)
+        ctx.model, ctx.n_net = model, n_net
         ctx.need_dw = any(p.requires_grad for p in params)
-        ctx.save_for_backward(A, film, D, flat.detach().clone() if ctx.need_dw else flat.detach())
+        ctx.save_for_backward(Z, D, flat.detach().clone() if ctx.need_dw else flat.detach(), mflat)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        A, film, D, flat = ctx.saved_tensors
-        dA, dfilm, dparams = ctx.model._plan().film_backward(A, film, D, flat, dout, need_dw=ctx.need_dw)
-        grads = ctx.model._split_flat(dparams) if ctx.need_dw else [None] * ctx.n_params
-        return (None, dA, dfilm, None, *grads)
+        Z, D, flat, mflat = ctx.saved_tensors
+        dZ, dparams, dmap = ctx.model._plan().film_model_backward(Z, D, flat, mflat, dout, need_dw=ctx.need_dw)
+        grads = ctx.model._split_grads(dparams, dmap) if ctx.need_dw else [None] * (ctx.n_net + len(ctx.model._map_params()))
+        return (None, dZ, None, None, *grads)
 
 
 class _FilmFusedLossFn(torch.autograd.Function):
-    """(mse + cosine, mse, 0, cosine) = criterion(core(A, film, D), target, weight) with the gradients produced in
-    the same fused launch; backward only rescales them."""
+    """(loss, mse, prior, cosine) = criterion(model(Z, D), target, weight[, Z]) with every gradient produced by the same
+    call; backward only rescales them."""
 
     @staticmethod
-    def forward(ctx, model, loss_kind, beta, target, weight, A, film, D, *params):
-        flat = model._flat_params()
+    def forward(ctx, model, loss_kind, alpha, beta, target, weight, Z, D, n_net, *params):
         need_dw = any(p.requires_grad for p in params)
-        terms, dA, dfilm, dparams, _ = model._plan().film_forward_loss_backward(
-            A, film, D, flat, target, weight, loss_kind=loss_kind, beta=beta, need_dw=need_dw)
-        ctx.model = model
-        ctx.n_params = len(params)
-        ctx.need_dw = need_dw
-        ctx.dA, ctx.dfilm, ctx.dparams = dA, dfilm, dparams
+        terms, dZ, dparams, dmap, _ = model._plan().film_model_forward_loss_backward(
+            Z, D, model._flat_params(), model._map_flat(), target, weight, loss_kind=loss_kind, alpha=alpha, beta=beta,
+            need_dw=need_dw)
+        ctx.model, ctx.n_net, ctx.need_dw = model, n_net, need_dw
+        ctx.dZ, ctx.dparams, ctx.dmap = dZ, dparams, dmap
         return terms
 
     @staticmethod
     def backward(ctx, gterms):
         s = gterms[0]  # only the total carries the fused gradient
-        grads = ctx.model._split_flat(ctx.dparams * s) if ctx.need_dw else [None] * ctx.n_params
-        return (None, None, None, None, None, ctx.dA * s, ctx.dfilm * s, None, *grads)
+        if ctx.need_dw:
+            grads = ctx.model._split_grads(ctx.dparams * s, ctx.dmap * s)
+        else:
+            grads = [None] * (ctx.n_net + len(ctx.model._map_params()))
+        return (None, None, None, None, None, None, ctx.dZ * s, None, None, *grads)
 
 
 # --------------------------------------------------------------------------------------------
@@ -215,12 +216,30 @@ class _RENIFiLMBase(_RENIConcatBase):
                     "FiLM with equivariance 'None' cannot run in the reference either: in_features / mn_in_features "
                     "are swapped relative to NoInvarianceFiLM's outputs (RENI.py:449-452, 549-552)")
             plan = ops.Plan(self.equivariance, self.ndims, self.siren_hidden_features, self.siren_hidden_layers - 1,
-                            self.out_features, True, self.output_activation, 1.0, 1.0, key, conditioning="film")
+                            self.out_features, True, self.output_activation, 1.0, 1.0, key, conditioning="film",
+                            mapping_layers=self.mapping_network_layers, mapping_features=self.mapping_network_features)
             assert plan.n_params == sum(p.numel() for p in self._net_params())
+            assert plan.n_map_params == sum(p.numel() for p in self._map_params())
             self._plans[key] = plan
         return plan
 
-    # ---- per-image glue (torch, differentiable) ----------------------------------------------
+    # mapping-network parameters in state-dict order = the `map_params` layout of reni_film_model_*
+    def _map_params(self) -> List[nn.Parameter]:
+        return list(self.mapping_network.parameters())
+
+    def _map_flat(self) -> torch.Tensor:
+        return torch.cat([p.detach().reshape(-1).float() for p in self._map_params()])
+
+    def _split_grads(self, dparams: torch.Tensor, dmap: torch.Tensor):
+        out = self._split_flat(dparams)
+        o = 0
+        for p in self._map_params():
+            n = p.numel()
+            out.append(dmap[o:o + n].view(p.shape) if p.requires_grad else None)
+            o += n
+        return out
+
+    # ---- per-image glue restated in torch (reference for the HIP glue; see the module docstring) ----------------------------------------------
     def _glue(self, Z: torch.Tensor):
         """Z [B,ND,3] -> (A [B,H,8], film [B,L,2,H]); see the module docstring."""
         B, H, nF = Z.shape[0], self.siren_hidden_features, len(self.net)
@@ -250,20 +269,17 @@ class _RENIFiLMBase(_RENIConcatBase):
         if Z.shape[0] != directions.shape[0] and directions.shape[0] != 1:
             raise AssertionError("latent batch and directions batch differ")
         ops._require_cuda(Z, directions)
-        A, film = self._glue(Z)
-        return _FilmDecodeFn.apply(self, A, film, directions, *self._net_params())
+        net = self._net_params()
+        return _FilmDecodeFn.apply(self, Z, directions, len(net), *net, *self._map_params())
 
     def fused_loss(self, Z, directions, target, weight, loss_kind="mse", alpha=0.0, beta=0.0):
-        """criterion(model(Z, D), target, weight[, Z]) with ONE fused forward+loss+backward launch for the per-sample
-        work; returns (loss, mse, prior, cosine).  The latent prior alpha |Z|^2 of RENITestLoss is per-image work
-        and is added here."""
+        """criterion(model(Z, D), target, weight[, Z]) as ONE library call (mapping network, fused forward+loss+
+        backward, glue backward); returns (loss, mse, prior, cosine); ``.backward()`` on element 0 delivers the
+        gradients the call already computed."""
         ops._require_cuda(Z, directions, target, weight)
-        A, film = self._glue(Z)
-        t = _FilmFusedLossFn.apply(self, loss_kind, float(beta), target, weight, A, film, directions, *self._net_params())
-        if loss_kind == "test":
-            prior = float(alpha) * torch.pow(Z, 2).sum()
-            return torch.stack((t[0] + prior, t[1], prior, t[3]))
-        return t
+        net = self._net_params()
+        return _FilmFusedLossFn.apply(self, loss_kind, float(alpha), float(beta), target, weight, Z, directions, len(net),
+                                      *net, *self._map_params())
 
     def forward_with_frequencies_phase_shifts(self, x, frequencies, phase_shifts):
         """The reference's per-pixel evaluation (RENI.py:665-676) for callers that pass hand-built tensors; the

@@ -31,7 +31,7 @@ class Plan:
     def __init__(self, equivariance: str, ndims: int, hidden_features: int, hidden_layers: int,
                  out_features: int = 3, last_layer_linear: bool = True, output_activation=None,
                  first_omega_0: float = 30.0, hidden_omega_0: float = 30.0, dtype: str = "f32",
-                 conditioning: str = "concat"):
+                 conditioning: str = "concat", mapping_layers: int = 0, mapping_features: int = 0):
         lib = _lib.load()
         if equivariance not in _lib.EQ:
             raise ValueError(f"equivariance {equivariance!r}")
@@ -40,7 +40,8 @@ class Plan:
         self.desc = _lib.reni_desc(_lib.EQ[equivariance], ndims, hidden_features, hidden_layers, out_features,
                                    1 if last_layer_linear else 0, _lib.ACT[output_activation],
                                    float(first_omega_0), float(hidden_omega_0), _lib.DTYPE[dtype],
-                                   {"concat": _lib.COND_CONCAT, "film": _lib.COND_FILM}[conditioning])
+                                   {"concat": _lib.COND_CONCAT, "film": _lib.COND_FILM}[conditioning],
+                                   int(mapping_layers), int(mapping_features))
         self.conditioning = conditioning
         self.hidden_features = hidden_features
         self.hidden_layers = hidden_layers
@@ -50,6 +51,7 @@ class Plan:
         self.ndims = ndims
         self.dtype = dtype
         self.n_params = int(lib.reni_param_count(self._h))
+        self.n_map_params = int(lib.reni_film_map_param_count(self._h))
         self.in_features = int(lib.reni_in_features(self._h))
         self._ws = {}
 
@@ -238,6 +240,70 @@ class Plan:
             self._h, B, P, Dc.data_ptr(), dbs, A.data_ptr(), film.data_ptr(), params.data_ptr(), dout.data_ptr(), flags,
             dA.data_ptr(), dfilm.data_ptr(), dparams.data_ptr() if dparams is not None else None, wp, wn, stream))
         return dA, dfilm, dparams
+
+
+    # ---- FiLM, whole model (per-image glue in HIP too): latents + mapping-network parameters in, their gradients out
+    def film_model_forward(self, Z, D, params, map_params):
+        _require_cuda(Z, D, params, map_params)
+        Z = _f32c(Z); params = _f32c(params); map_params = _f32c(map_params)
+        B, P, Dc, dbs = self._grid_args(Z, D)
+        assert params.numel() == self.n_params and map_params.numel() == self.n_map_params
+        out = torch.empty(B, P, 3, dtype=torch.float32, device=Z.device)
+        ws = self.workspace(B, P, 0, Z.device)
+        wp, wn = self._aligned_ptr(ws)
+        stream = torch.cuda.current_stream(Z.device).cuda_stream
+        _lib.check(self.lib.reni_film_model_forward(self._h, B, P, Z.data_ptr(), Dc.data_ptr(), dbs, params.data_ptr(),
+                                                    map_params.data_ptr(), out.data_ptr(), wp, wn, stream))
+        return out
+
+    def film_model_forward_loss_backward(self, Z, D, params, map_params, target, weight, loss_kind="mse", alpha=0.0,
+                                         beta=0.0, need_dw=True, want_out=False):
+        """-> (loss_terms[4], dZ, dparams or None, dmap_params or None, out or None)"""
+        _require_cuda(Z, D, params, map_params, target, weight)
+        Z = _f32c(Z); params = _f32c(params); map_params = _f32c(map_params)
+        B, P, Dc, dbs = self._grid_args(Z, D)
+        if target.dtype != torch.float32:
+            target = target.float()
+        if weight.dtype != torch.float32:
+            weight = weight.float()
+        target = target.expand(B, P, 3)
+        weight = weight.expand(B, P, 3)
+        ts = (ctypes.c_int64 * 3)(*target.stride())
+        wst = (ctypes.c_int64 * 3)(*weight.stride())
+        flags = (_lib.NEED_DW if need_dw else 0) | _lib.NEED_DZ
+        dev = Z.device
+        loss_terms = torch.empty(4, dtype=torch.float32, device=dev)
+        dZ = torch.empty_like(Z)
+        dparams = torch.empty(self.n_params, dtype=torch.float32, device=dev) if need_dw else None
+        dmap = torch.empty(self.n_map_params, dtype=torch.float32, device=dev) if need_dw else None
+        out = torch.empty(B, P, 3, dtype=torch.float32, device=dev) if want_out else None
+        ws = self.workspace(B, P, flags, dev)
+        wp, wn = self._aligned_ptr(ws)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        kind = {"mse": _lib.LOSS_MSE, "test": _lib.LOSS_TEST}[loss_kind]
+        _lib.check(self.lib.reni_film_model_forward_loss_backward(
+            self._h, B, P, Z.data_ptr(), Dc.data_ptr(), dbs, params.data_ptr(), map_params.data_ptr(), target.data_ptr(), ts,
+            weight.data_ptr(), wst, kind, float(alpha), float(beta), flags, out.data_ptr() if out is not None else None,
+            loss_terms.data_ptr(), dZ.data_ptr(), dparams.data_ptr() if need_dw else None,
+            dmap.data_ptr() if need_dw else None, wp, wn, stream))
+        return loss_terms, dZ, dparams, dmap, out
+
+    def film_model_backward(self, Z, D, params, map_params, dout, need_dw=True):
+        _require_cuda(Z, D, params, map_params, dout)
+        Z = _f32c(Z); params = _f32c(params); map_params = _f32c(map_params); dout = _f32c(dout)
+        B, P, Dc, dbs = self._grid_args(Z, D)
+        flags = (_lib.NEED_DW if need_dw else 0) | _lib.NEED_DZ
+        dev = Z.device
+        dZ = torch.empty_like(Z)
+        dparams = torch.empty(self.n_params, dtype=torch.float32, device=dev) if need_dw else None
+        dmap = torch.empty(self.n_map_params, dtype=torch.float32, device=dev) if need_dw else None
+        ws = self.workspace(B, P, flags, dev)
+        wp, wn = self._aligned_ptr(ws)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(self.lib.reni_film_model_backward(
+            self._h, B, P, Z.data_ptr(), Dc.data_ptr(), dbs, params.data_ptr(), map_params.data_ptr(), dout.data_ptr(), flags,
+            dZ.data_ptr(), dparams.data_ptr() if need_dw else None, dmap.data_ptr() if need_dw else None, wp, wn, stream))
+        return dZ, dparams, dmap
 
 
 def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,

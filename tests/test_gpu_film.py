@@ -190,3 +190,31 @@ def test_film_stream_runs_many_small_images(dev, H, nF):
     got = _grads(m)
     for k, v in ref["grads"].items():
         assert O.rel_l2(got[k].numpy(), v.numpy()) <= 3e-2, k
+
+
+def test_film_core_entry_points_with_caller_owned_glue(dev):
+    """reni_film_forward / reni_film_forward_loss_backward (the per-sample core, for callers that own the per-image
+    glue): A, film from the torch restatement (film.py::_glue), dA / dfilm carried back by torch autograd -- the latent
+    gradient and the mapping network's gradients must equal the reference's (G11)."""
+    g = load_golden("g11_film_so2_ad.npz")
+    m, spec = _model_from_golden(g, dev)
+    W = int(g["W"])
+    D = O.get_directions(W).to(dev)
+    S = O.get_sineweight(W).to(dev)
+    T = torch.from_numpy(g["target"]).to(dev)
+    Z = torch.from_numpy(g["Z"]).to(dev).requires_grad_(True)
+    A, film = m._glue(Z)
+    plan, flat = m._plan(), m._flat_params()
+    out = plan.film_forward(A.detach(), film.detach(), D, flat)
+    assert float((out.cpu() - torch.from_numpy(g["out"])).abs().max()) <= 1e-5
+    terms, dA, dfilm, dparams, _ = plan.film_forward_loss_backward(A.detach(), film.detach(), D, flat, T, S)
+    assert abs(float(terms[0]) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    torch.autograd.backward([A, film], [dA, dfilm])
+    assert O.rel_l2(Z.grad.cpu().numpy(), g["dZ"]) <= 2e-5
+    for k, p in m.mapping_network.named_parameters():
+        assert O.rel_l2(p.grad.cpu().numpy(), g["g.mapping_network." + k]) <= 2e-5, k
+    # hidden / head slots of the flat gradient come from the kernels; the first layer's slot is the caller's (zero)
+    n_first = m.net[0].layer.weight.numel() + m.net[0].layer.bias.numel()
+    assert float(dparams[:n_first].abs().max()) == 0.0
+    got = dparams[n_first:n_first + m.net[1].layer.weight.numel()].view_as(m.net[1].layer.weight)
+    assert O.rel_l2(got.cpu().numpy(), g["g.net.1.layer.weight"]) <= 2e-5
