@@ -104,7 +104,7 @@ def test_g4_c2_shape_golden(dev, dtype):
 @pytest.mark.parametrize("cfg", [
     dict(eq="SO2", nd=9, H=64, L=0), dict(eq="SO2", nd=36, H=128, L=5), dict(eq="SO3", nd=12, H=128, L=2),
     dict(eq="None", nd=5, H=32, L=2), dict(eq="SO2", nd=49, H=128, L=5, act="exp"),
-    dict(eq="SO2", nd=36, H=256, L=5), dict(eq="SO3", nd=9, H=256, L=1)])
+    dict(eq="SO2", nd=36, H=256, L=5), dict(eq="SO2", nd=9, H=128, L=7), dict(eq="SO3", nd=9, H=256, L=1)])
 def test_random_problems_vs_oracle(dev, dtype, cfg):
     """ragged P (not a multiple of the 128-sample tile), arbitrary (non-grid) directions."""
     spec = O.DecoderSpec(cfg["nd"], cfg["eq"], cfg["H"], cfg["L"], 3, True, cfg.get("act", "tanh"))
