@@ -19,6 +19,7 @@ struct MainArgs {
   const float* D;
   long long d_bstride;
   const float* Apre;  // [B][H][8] per-image affine map of the first layer
+  const char* afrag;  // the same as split-bf16 MFMA fragments (PrepArgs::afrag), persistent training path
   const char* wimg;   // packed weight images
   unsigned fwd_off[MAX_LAYERS + 2];  // byte offsets into wimg, index 1..L hidden, L+1 head
   unsigned bwd_off[MAX_LAYERS + 2];
@@ -70,6 +71,7 @@ struct PrepArgs {
   const float* b0;
   float* xconst;  // [B][F_in]
   float* A;       // [B][H][8]
+  char* afrag;    // optional [B][H/32][64 lanes][16 B]: A_b as split-bf16 MFMA A operands (persistent training kernel)
   int eq, nd, F_in, H;
 };
 
