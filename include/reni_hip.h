@@ -204,6 +204,32 @@ int reni_profile_read(double* total_ms, int64_t* launches, int32_t reset);
  * lane l reads at byte address 8*l (mode 0) or lane_addr_host[l] (mode 1); out_host[4*l + e] = element e. */
 int reni_probe_tr(const int32_t* lane_addr_host, int32_t mode, uint16_t* out_host);
 
+/* ---- environment-map Blinn-Phong shading of a G-buffer (FIT_INVERSE task) ------------------------------------
+ * Replaces the arithmetic of blinn_phong_shading_env_map (src/utils/pytorch3d_envmap_shader.py:46-116) behind the
+ * two interpolate_face_attributes calls (:68-73): the caller hands over the per-pixel interpolated vertex normals
+ * and positions (the rasteriser is pytorch3d's, outside this library).
+ *   normals, positions : [NP][3] device, NP = render pixels; NOT normalised (the library applies F.normalize(eps=1e-6)
+ *                        as :82,:93 do); rows of zeros where no face covers the pixel (pix_to_face < 0)
+ *   cam_*              : cameras.get_camera_center() (:78)
+ *   light_dirs         : [J][3] unit directions of the environment-map texels (EnvironmentMap.directions, :75) of image
+ *                        b at light_dirs + b * dirs_batch_stride (floats; 0 = one grid shared by all images, which is
+ *                        what the reference's directions.repeat(B,1,1) amounts to, RENI_module.py:376)
+ *   light_colors       : [B][J][3] EnvironmentMap.environment_map = map * sineweight (:41,:77)
+ *   shininess, kd, ks  : materials.shininess (:79, 500 in build_renderer :186), kd, ks = 1 - kd (:199)
+ *   colors             : [B][NP][3] = kd * diffuse + (s+2)/(4(2-exp(-s/2))) * ks * specular   (:112-115)
+ * reni_envmap_shade_backward returns d loss / d light_colors [B][J][3] for an upstream d loss / d colors [B][NP][3]
+ * (the only tensor of the shader that carries a gradient in the reference: the mesh and the grid are constants).
+ * ws: reni_envmap_shade_workspace_bytes(B, NP, J) bytes, 256-byte aligned, for the partial sums. */
+size_t reni_envmap_shade_workspace_bytes(int64_t B, int64_t NP, int64_t J);
+int reni_envmap_shade(int64_t B, int64_t NP, int64_t J, const float* normals, const float* positions, float cam_x,
+                      float cam_y, float cam_z, const float* light_dirs, int64_t dirs_batch_stride,
+                      const float* light_colors, float shininess, float kd, float ks, float* colors, void* ws,
+                      size_t ws_bytes, void* stream);
+int reni_envmap_shade_backward(int64_t B, int64_t NP, int64_t J, const float* normals, const float* positions, float cam_x,
+                               float cam_y, float cam_z, const float* light_dirs, int64_t dirs_batch_stride,
+                               const float* dcolors, float shininess, float kd, float ks, float* dlight_colors, void* ws,
+                               size_t ws_bytes, void* stream);
+
 /* Launch geometry chosen for (B,P): workgroups, threads, dynamic LDS bytes (diagnostics). */
 int reni_launch_info(const reni_plan* plan, int64_t B, int64_t P, int32_t* info4);
 

@@ -629,3 +629,36 @@ def synthetic_images(indices: Sequence[int], height: int, width: int) -> torch.T
 def rel_l2(a, b) -> float:
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+# ---------------------------------------------------------------------------------------------
+# environment-map Blinn-Phong shading (FIT_INVERSE): src/utils/pytorch3d_envmap_shader.py:46-116
+# ---------------------------------------------------------------------------------------------
+def interpolate_face_attributes(pix_to_face, bary_coords, face_attrs):
+    """pytorch3d.ops.interpolate_face_attributes as documented (pytorch3d is NOT under /root/reference; pinned
+    0.7.0 by the reference's environment.yml): out[n,h,w,k,:] = sum_i bary[n,h,w,k,i] * face_attrs[pix_to_face, i, :],
+    zeros where pix_to_face < 0.  pix_to_face [N,H,W,K] int64, bary_coords [N,H,W,K,3], face_attrs [F,3,D]."""
+    mask = pix_to_face < 0
+    idx = pix_to_face.clamp(min=0)
+    attrs = face_attrs[idx]                                   # [N,H,W,K,3,D]
+    out = (bary_coords[..., None] * attrs).sum(dim=-2)
+    return out.masked_fill(mask[..., None], 0.0)
+
+
+def blinn_phong_gbuffer(pixel_normals, pixel_positions, camera_center, light_directions, light_colors,
+                        shininess, kd, ks, dtype=torch.float64):
+    """Restatement of blinn_phong_shading_env_map behind the interpolation (pytorch3d_envmap_shader.py:75-115).
+    pixel_normals / pixel_positions [NP,3] (interpolated, not normalised), camera_center [3],
+    light_directions [B,J,3], light_colors [B,J,3] (= map * sineweight, :41) -> colors [B,NP,3]."""
+    N = torch.nn.functional.normalize(pixel_normals.to(dtype), p=2, dim=-1, eps=1e-6)            # :82
+    V = torch.nn.functional.normalize(camera_center.to(dtype)[None] - pixel_positions.to(dtype), p=2, dim=-1, eps=1e-6)  # :91-93
+    L = light_directions.to(dtype)
+    C = light_colors.to(dtype)
+    s = torch.as_tensor(shininess, dtype=dtype)
+    diffuse = torch.einsum("pk,bjk->bpj", N, L).clamp(0.0, 1.0)                                  # :87-88
+    diffuse = torch.einsum("bjk,bpj->bpk", C, diffuse)                                           # :90
+    Hv = torch.nn.functional.normalize(V[None, :, None, :] + L[:, None, :, :], p=2, dim=-1, eps=1e-6)  # :105-107
+    spec = torch.einsum("pk,bpjk->bpj", N, Hv).clamp(0.0, 1.0) ** s                              # :108-110
+    specular = torch.einsum("bjk,bpj->bpk", C, spec)                                             # :111
+    norm = (s + 2) / (4 * (2 - torch.exp(-s / 2)))                                               # :112-114
+    return kd * diffuse + norm * ks * specular                                                   # :115

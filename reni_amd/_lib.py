@@ -29,6 +29,7 @@ EXPORTS = (
     "reni_film_forward", "reni_film_forward_loss_backward", "reni_film_backward",
     "reni_film_map_param_count", "reni_film_model_forward", "reni_film_model_forward_loss_backward",
     "reni_film_model_backward",
+    "reni_envmap_shade_workspace_bytes", "reni_envmap_shade", "reni_envmap_shade_backward",
 )
 
 
@@ -115,6 +116,12 @@ def load():
     lib.reni_profile_enable.restype = c_int32
     lib.reni_profile_read.argtypes = [POINTER(ctypes.c_double), POINTER(c_int64), c_int32]
     lib.reni_profile_read.restype = c_int32
+    lib.reni_envmap_shade_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]
+    lib.reni_envmap_shade_workspace_bytes.restype = c_size_t
+    for fn in (lib.reni_envmap_shade, lib.reni_envmap_shade_backward):
+        fn.argtypes = [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_int64,
+                       c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]
+        fn.restype = c_int32
     _lib = lib
     return lib
 

@@ -59,6 +59,9 @@ struct MainArgs {
   int kmax;
 };
 
+// sets reni_last_error()'s thread-local message and returns `code` (defined next to the C ABI, reni_capi.inc)
+int reni_set_error(int code, const char* msg);
+
 // host launchers of the fused kernel, one per translation unit (reni_device.inc)
 hipError_t launch_main_f32(int H, int mode, const MainArgs& a, int nwg, hipStream_t s);
 hipError_t launch_main_bf16(int H, int mode, const MainArgs& a, int nwg, hipStream_t s);

@@ -14,7 +14,8 @@ MINMAX = (-18.0536, 11.4633)
 class SyntheticEnvMapDataset(Dataset):
     def __init__(self, n_images, height, width, seed_base=1234):
         self.n, self.h, self.w, self.seed_base = n_images, height, width, seed_base
-        self.unnormalise = None
+        from .custom_transforms import UnMinMaxNormlise
+        self.unnormalise = UnMinMaxNormlise(MINMAX)  # datasets.py:80-86: inverse of the minmax-log transform
 
     def __len__(self):
         return self.n

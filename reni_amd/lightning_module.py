@@ -5,8 +5,9 @@ re-implemented on the fused HIP path.
 
 pytorch_lightning is not installed here; when it is importable ``RENI`` derives from
 ``pl.LightningModule`` and can be handed to a ``pl.Trainer``; otherwise it derives from a small
-duck-typed base and ``reni_amd.trainer.fit`` drives it.  The FIT_INVERSE task needs the PyTorch3D
-renderer, which is outside this build's scope.
+duck-typed base and ``reni_amd.trainer.fit`` drives it.  The FIT_INVERSE task shades through
+``reni_amd.envmap_shader`` (HIP); the rasteriser that produces its G-buffer is pytorch3d's and outside this
+build, so the renderer is handed in with ``set_renderer`` (a stored G-buffer, or a pytorch3d MeshRenderer).
 """
 from __future__ import annotations
 
@@ -71,6 +72,7 @@ class RENI(_Base):
         self.sineweight = get_sineweight(self.cur_res[1])  # (1, H*W, 3)
         self.setup_for_task(self.task)
         self.mask = None
+        self.renderer, self.render_kwargs, self.gt_renders = None, {}, None
         if self.task == "FIT_LATENT" and self.config.RENI.FIT_LATENT.APPLY_MASK:
             self.mask = get_mask(self.cur_res[1], self.config.RENI.FIT_LATENT.MASK_PATH)  # (1, H*W, 3)
         self._grid_cache = {}
@@ -84,8 +86,38 @@ class RENI(_Base):
         self.model.load_state_dict(state_dict)
 
     def on_fit_start(self):
-        if self.task == "FIT_INVERSE":
-            raise NotImplementedError("FIT_INVERSE needs the PyTorch3D env-map renderer (out of scope)")
+        if self.task == "FIT_INVERSE" and self.renderer is None:
+            raise NotImplementedError("FIT_INVERSE renders through an environment-map shader: call set_renderer() with "
+                                      "reni_amd.envmap_shader.GBufferRenderer (stored G-buffer) or build_renderer's "
+                                      "pytorch3d MeshRenderer first")
+
+    # ------------------------------------------------------------------ FIT_INVERSE (RENI_module.py:65-73, 363-396)
+    def set_renderer(self, renderer, render_kwargs=None):
+        """`renderer(envmap=EnvironmentMap, **render_kwargs) -> (render [B,Hr,Wr,3], normals)`: the call the reference
+        makes on its pytorch3d MeshRenderer (RENI_module.py:393-395).  Generates the ground-truth renders."""
+        self.renderer = renderer
+        self.render_kwargs = dict(render_kwargs or {})
+        self.generate_gt_renders()
+
+    def get_render(self, model_output, directions, sineweight):
+        from .envmap_shader import EnvironmentMap
+        B = model_output.shape[0]
+        envmap = EnvironmentMap(environment_map=model_output, directions=directions.expand(B, -1, -1), sineweight=sineweight)
+        render, _ = self.renderer(envmap=envmap, **self.render_kwargs)
+        return render
+
+    def generate_gt_renders(self, device=None):
+        """RENI_module.py:363-384: render every (un-normalised) dataset image once."""
+        device = device or ("cuda" if torch.cuda.is_available() else "cpu")
+        with torch.no_grad():
+            out = []
+            for i in range(len(self.dataset)):
+                imgs, _ = self.dataset[i]
+                imgs = self.dataset.unnormalise(imgs.unsqueeze(0).to(device))
+                imgs = imgs.permute(0, 2, 3, 1).reshape(1, -1, 3)
+                directions, sineweight = self._grids(imgs)
+                out.append(self.get_render(imgs, directions, sineweight))
+            self.gt_renders = torch.cat(out, dim=0)
 
     # ------------------------------------------------------------------ grids on the device
     def _grids(self, like: torch.Tensor):
@@ -123,8 +155,15 @@ class RENI(_Base):
             else:
                 Z = self.model.mu[idx, :, :]
 
-        if self.task == "FIT_INVERSE":
-            raise NotImplementedError("FIT_INVERSE needs the PyTorch3D env-map renderer (out of scope)")
+        if self.task == "FIT_INVERSE":  # RENI_module.py:105-112, 135-144
+            if self.renderer is None:
+                raise NotImplementedError("FIT_INVERSE: call set_renderer() first (see on_fit_start)")
+            gt = self.gt_renders[idx, :, :, :]
+            model_output = self.model(Z, directions)
+            model_output = self.dataset.unnormalise(model_output)
+            model_output = self.get_render(model_output, directions, sineweight)
+            loss, mse_loss, prior_loss, cosine_loss = self.criterion(model_output, gt, Z)
+            return {"loss": loss, "mse_loss": mse_loss, "prior_loss": prior_loss, "cosine_loss": cosine_loss}
 
         if self.task == "FIT_DECODER":
             if self.model_type == "AutoDecoder":

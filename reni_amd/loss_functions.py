@@ -81,7 +81,7 @@ class RENITestLoss(object):
 
 
 class RENITestLossInverse(object):
-    """loss_functions.py:73-85 (used by the FIT_INVERSE task, whose renderer is out of scope)."""
+    """loss_functions.py:73-85 (FIT_INVERSE: plain MSE + prior + cosine similarity on the renders)."""
 
     def __init__(self, alpha=1, beta=1):
         self.alpha = alpha

@@ -335,3 +335,47 @@ def profile_read(reset: bool = True):
     n = ctypes.c_int64(0)
     _lib.check(_lib.load().reni_profile_read(ctypes.byref(tot), ctypes.byref(n), 1 if reset else 0))
     return tot.value, n.value
+
+
+def _shade_call(forward: bool, normals, positions, camera_center, light_dirs, src, shininess, kd, ks):
+    """reni_envmap_shade / reni_envmap_shade_backward (include/reni_hip.h).  normals, positions [NP,3];
+    light_dirs [J,3] (shared grid) or [B,J,3]; src = light colours [B,J,3] (forward) or d colours [B,NP,3] (backward)."""
+    _require_cuda(normals, positions, light_dirs, src)
+    lib = _lib.load()
+    f32 = torch.float32
+    normals = normals.to(f32).contiguous(); positions = positions.to(f32).contiguous()
+    light_dirs = light_dirs.to(f32).contiguous(); src = src.to(f32).contiguous()
+    NP = normals.shape[0]
+    if normals.shape != (NP, 3) or positions.shape != (NP, 3):
+        raise ValueError("normals and positions must be [NP, 3]")
+    B = src.shape[0]
+    if light_dirs.dim() == 2:
+        J, stride = light_dirs.shape[0], 0
+    else:
+        if light_dirs.shape[0] != B:
+            raise ValueError("light_dirs batch size must match the colours'")
+        J, stride = light_dirs.shape[1], light_dirs.shape[1] * 3
+    want = (B, J, 3) if forward else (B, NP, 3)
+    if tuple(src.shape) != want:
+        raise ValueError(f"expected a {want} tensor, got {tuple(src.shape)}")
+    cam = [float(x) for x in torch.as_tensor(camera_center).reshape(-1)[:3].tolist()]
+    out = torch.empty((B, NP, 3) if forward else (B, J, 3), dtype=f32, device=src.device)
+    nbytes = int(lib.reni_envmap_shade_workspace_bytes(B, NP, J))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=src.device)
+    stream = torch.cuda.current_stream(src.device).cuda_stream
+    fn = lib.reni_envmap_shade if forward else lib.reni_envmap_shade_backward
+    with torch.cuda.device(src.device):
+        _lib.check(fn(B, NP, J, normals.data_ptr(), positions.data_ptr(), cam[0], cam[1], cam[2], light_dirs.data_ptr(),
+                      stride, src.data_ptr(), float(shininess), float(kd), float(ks), out.data_ptr(), ws.data_ptr(), nbytes,
+                      stream))
+    return out
+
+
+def envmap_shade(normals, positions, camera_center, light_dirs, light_colors, shininess, kd, ks):
+    """colors [B,NP,3] of the Blinn-Phong environment-map shader (pytorch3d_envmap_shader.py:75-115)."""
+    return _shade_call(True, normals, positions, camera_center, light_dirs, light_colors, shininess, kd, ks)
+
+
+def envmap_shade_backward(normals, positions, camera_center, light_dirs, dcolors, shininess, kd, ks):
+    """d loss / d light_colors [B,J,3] for an upstream d loss / d colors [B,NP,3]."""
+    return _shade_call(False, normals, positions, camera_center, light_dirs, dcolors, shininess, kd, ks)

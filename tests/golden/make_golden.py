@@ -382,8 +382,73 @@ def g12():
          batch=batch.numpy(), unnorm_batch=un.numpy(), srgb1=srgb1.numpy(), srgb2=srgb2.numpy())
 
 
+def g13():
+    """G13: the reference's blinn_phong_shading_env_map (pytorch3d_envmap_shader.py:46-116) on a synthetic G-buffer.
+    pytorch3d is not installed: its names are stubbed so the module imports, and interpolate_face_attributes -- the
+    one pytorch3d function the shading routine calls -- is the oracle's restatement of its documented behaviour.
+    Everything after the interpolation (normalisation, einsums, clamp, pow, Blinn-Phong normalisation) is the
+    reference's own code running here."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import reni_oracle as O
+
+    class _Any(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return type(k, (), {})
+    for name in ("pytorch3d", "pytorch3d.structures", "pytorch3d.renderer", "pytorch3d.common", "pytorch3d.renderer.utils",
+                 "pytorch3d.ops", "pytorch3d.renderer.mesh", "pytorch3d.renderer.mesh.rasterizer", "pytorch3d.io",
+                 "pytorch3d.transforms"):
+        sys.modules[name] = _Any(name)
+    sys.modules["pytorch3d.ops"].interpolate_face_attributes = O.interpolate_face_attributes
+    from src.utils import pytorch3d_envmap_shader as ref_shader
+
+    gen = torch.Generator().manual_seed(13)
+    Vn, F, Hr, Wr, B = 40, 60, 12, 10, 3
+    verts = torch.randn(Vn, 3, generator=gen) * 0.5
+    vnorm = torch.nn.functional.normalize(torch.randn(Vn, 3, generator=gen), dim=-1)
+    faces = torch.randint(0, Vn, (F, 3), generator=gen)
+    pix_to_face = torch.randint(-1, F, (1, Hr, Wr, 1), generator=gen)
+    pix_to_face[0, 0, :3, 0] = -1
+    bary = torch.rand(1, Hr, Wr, 1, 3, generator=gen)
+    bary = bary / bary.sum(-1, keepdim=True)
+    D = ref_utils.get_directions(16)          # [1, 8*16, 3]
+    sw = ref_utils.get_sineweight(16)
+    J = D.shape[1]
+    env = torch.exp(torch.randn(B, J, 3, generator=gen))   # positive HDR-like radiance
+    cam = torch.tensor([[0.0, 0.0, 2.0]])
+    shin, kd = 500.0, 0.5
+
+    class Meshes:
+        def verts_packed(self): return verts
+        def faces_packed(self): return faces
+        def verts_normals_packed(self): return vnorm
+    class Frag:
+        pass
+    fr = Frag(); fr.pix_to_face = pix_to_face; fr.bary_coords = bary
+    class Cam:
+        def get_camera_center(self): return cam
+    class Mat:
+        shininess = torch.tensor([shin])
+    outs = {}
+    for tag, s_ in (("", shin), ("_s20", 20.0)):
+        Mat.shininess = torch.tensor([s_])
+        envmap = ref_shader.EnvironmentMap(environment_map=env.clone().requires_grad_(True), directions=D.repeat(B, 1, 1),
+                                           sineweight=sw.repeat(B, 1, 1))
+        colors, pn = ref_shader.blinn_phong_shading_env_map("cpu", Meshes(), fr, envmap, Cam(), Mat(), kd, 1.0 - kd)
+        w = torch.randn(colors.shape, generator=torch.Generator().manual_seed(5))
+        (gC,) = torch.autograd.grad((colors * w).sum(), envmap.environment_map)
+        outs["colors" + tag] = colors.detach().numpy()
+        outs["dlight" + tag] = gC.numpy()
+        outs["upstream" + tag] = w.numpy()
+        outs["pixel_normals"] = pn.detach().numpy()
+    save("g13_envmap_shader.npz", verts=verts.numpy(), vnorm=vnorm.numpy(), faces=faces.numpy(),
+         pix_to_face=pix_to_face.numpy(), bary=bary.numpy(), directions=D.numpy(), sineweight=sw.numpy(), env=env.numpy(),
+         cam=cam.numpy(), shininess=np.float32(shin), kd=np.float32(kd), **outs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()

@@ -233,3 +233,27 @@ def test_hdr_transforms_match_reference(golden):
     np.testing.assert_allclose(utils.sRGB(x2).numpy(), g["srgb2"], rtol=0, atol=1e-6)
     with pytest.raises(NotImplementedError, match="torchvision"):
         transform_builder([("resize", [64, 128])])
+
+
+def test_envmap_shader_surface():
+    """reni_amd.envmap_shader mirrors src/utils/pytorch3d_envmap_shader.py: EnvironmentMap pre-multiplies the sine
+    weight (:41), the interpolation matches the oracle's, the shading itself has no CPU path, build_renderer needs
+    pytorch3d."""
+    import pytest
+    from oracle import reni_oracle as O
+    from reni_amd import _lib
+    from reni_amd import envmap_shader as es
+    g = torch.Generator().manual_seed(0)
+    env, sw, D = torch.rand(2, 8, 3, generator=g), torch.rand(2, 8, 3, generator=g), torch.randn(2, 8, 3, generator=g)
+    em = es.EnvironmentMap(environment_map=env, directions=D, sineweight=sw)
+    assert torch.equal(em.environment_map, env * sw) and em.directions is D
+    p2f = torch.randint(-1, 5, (1, 4, 3, 1), generator=g)
+    bary = torch.rand(1, 4, 3, 1, 3, generator=g)
+    attrs = torch.randn(5, 3, 3, generator=g)
+    assert torch.equal(es.interpolate_face_attributes(p2f, bary, attrs), O.interpolate_face_attributes(p2f, bary, attrs))
+    with pytest.raises(_lib.RENILibraryError):
+        es.blinn_phong_shading_gbuffer(torch.randn(5, 3), torch.randn(5, 3), torch.tensor([0.0, 0.0, 2.0]), em, 500.0, 0.5, 0.5)
+    with pytest.raises(ImportError):
+        es.build_renderer("teapot.obj", 90, 128, 0.5, "cpu")
+    r = es.GBufferRenderer(es.GBuffer(torch.randn(16, 3), torch.randn(16, 3), [0.0, 0.0, 2.0], 4), kd=0.3)
+    assert abs(r.ks - 0.7) < 1e-12 and r.shininess == 500.0 and r.gbuffer.image_size == (4, 4)

@@ -183,3 +183,35 @@ def test_g11_film_oracle_matches_reference(golden, tag):
     r2 = O.film_fwd_loss_bwd(spec, params, Z, D, T, S, "test", 1e-3, 1e-1)
     assert np.abs(np.array(r2["terms"]) - g["test_terms"]).max() <= 1e-6 * abs(g["test_terms"][0])
     assert O.rel_l2(r2["dZ"].numpy(), g["test_dZ"]) <= 5e-6
+
+
+def _g13_gbuffer(g):
+    verts, vnorm, faces = (torch.from_numpy(g[k]) for k in ("verts", "vnorm", "faces"))
+    p2f, bary = torch.from_numpy(g["pix_to_face"]), torch.from_numpy(g["bary"])
+    pn = O.interpolate_face_attributes(p2f, bary, vnorm[faces])[0, :, :, 0, :].reshape(-1, 3)
+    pp = O.interpolate_face_attributes(p2f, bary, verts[faces])[0, :, :, 0, :].reshape(-1, 3)
+    return pn, pp
+
+
+@pytest.mark.parametrize("tag,shin,rtol", [("", 500.0, 2e-4), ("_s20", 20.0, 2e-5)])
+def test_g13_envmap_shader_oracle_matches_reference(golden, tag, shin, rtol):
+    """The fp64 restatement of blinn_phong_shading_env_map against the reference's own fp32 run (colours, the
+    gradient w.r.t. the sine-weighted map, the normalised normals).  x ** 500 amplifies fp32 rounding of the
+    half-vector dot product 500-fold: 2e-4 of the largest colour is the reference's own fp32 noise floor."""
+    g = golden("g13_envmap_shader.npz")
+    pn, pp = _g13_gbuffer(g)
+    B = g["env"].shape[0]
+    L = torch.from_numpy(g["directions"]).repeat(B, 1, 1)
+    C = (torch.from_numpy(g["env"]) * torch.from_numpy(g["sineweight"])).double().requires_grad_(True)
+    col = O.blinn_phong_gbuffer(pn, pp, torch.from_numpy(g["cam"])[0], L, C, shin, float(g["kd"]), 1.0 - float(g["kd"]))
+    ref = torch.from_numpy(g["colors" + tag]).reshape(B, -1, 3).double()
+    assert (col - ref).abs().max() <= rtol * ref.abs().max()
+    w = torch.from_numpy(g["upstream" + tag]).reshape(B, -1, 3).double()
+    (gC,) = torch.autograd.grad((col * w).sum(), C)
+    gref = torch.from_numpy(g["dlight" + tag]).double()
+    assert (gC - gref).abs().max() <= rtol * gref.abs().max()
+    nrm = torch.nn.functional.normalize(pn, dim=-1, eps=1e-6)
+    assert np.allclose(nrm.numpy(), g["pixel_normals"][0].reshape(-1, 3), atol=1e-6)
+    # background pixels (pix_to_face < 0) render black
+    bg = torch.from_numpy(g["pix_to_face"]).reshape(-1) < 0
+    assert bg.any() and float(ref[:, bg].abs().max()) == 0.0 and float(col[:, bg].abs().max()) == 0.0
