@@ -47,8 +47,7 @@ DEV void normalize3(float (&v)[3]) {  // F.normalize(p=2, eps=1e-6): v / max(|v|
 DEV float shade_coeff(const float (&N)[3], const float (&V)[3], const float (&L)[3], float shin, float kd, float ksn) {
   const float nl = fminf(fmaxf(N[0] * L[0] + N[1] * L[1] + N[2] * L[2], 0.f), 1.f);        // :87-88
   const float hx = V[0] + L[0], hy = V[1] + L[1], hz = V[2] + L[2];                          // :105
-  const float hn = sqrtf(hx * hx + hy * hy + hz * hz);
-  const float inv = 1.f / fmaxf(hn, 1e-6f);                                                  // :107
+  const float inv = __builtin_amdgcn_rsqf(fmaxf(hx * hx + hy * hy + hz * hz, 1e-12f));       // 1 / max(|h|, 1e-6)  :107
   // normalise first, then dot, as the reference does
   const float nh = fminf(fmaxf(N[0] * (hx * inv) + N[1] * (hy * inv) + N[2] * (hz * inv), 0.f), 1.f);  // :108-109
   const float spec = __builtin_amdgcn_exp2f(shin * __builtin_amdgcn_logf(nh));               // pow(x, s), x in [0, 1]; 0 -> 0
