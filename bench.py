@@ -165,7 +165,7 @@ def main():
                        "parallelism": f"dp{world}", "loss_last_step": loss},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                          "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": traffic,
-                         "kernel": "k_reni_train_bf16<128>" if args.dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD>",
+                         "kernel": "k_reni_train_bf16<128,true>" if args.dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD>",
                          "kernel_avg_ms": kavg_ms,
                          "kernel_launches": kern_n, "flop_per_sample": FLOP_PER_SAMPLE},
         }

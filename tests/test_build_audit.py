@@ -34,10 +34,9 @@ def _isa(tu):
     return _ISA[tu]
 
 
-def test_training_kernel_agprs_only_in_hand_written_asm():
-    text = _isa("core")
-    fn = [x for x in re.split(r"\n\s*\.globl\s+", text) if x.startswith("_ZN4reni17k_reni_train_bf16")]
-    assert len(fn) == 1
+def _train_kernel_counts(text, mangled_prefix):
+    fn = [x for x in re.split(r"\n\s*\.globl\s+", text) if x.startswith(mangled_prefix)]
+    assert len(fn) == 1, mangled_prefix
     in_asm, touching, outside, scratch, mfma = False, 0, 0, 0, 0
     for line in fn[0].split("\n"):
         if "ASMSTART" in line:
@@ -54,9 +53,19 @@ def test_training_kernel_agprs_only_in_hand_written_asm():
                 outside += 0 if in_asm else 1
             if "scratch_" in code:
                 scratch += 1
+    return mfma, touching, outside, scratch
+
+
+def test_training_kernel_agprs_only_in_hand_written_asm():
+    text = _isa("core")
+    # k_reni_train_bf16<128, true>: the training instance owns the AGPRs by hand
+    mfma, touching, outside, scratch = _train_kernel_counts(text, "_ZN4reni17k_reni_train_bf16ILi128ELb1EEE")
     assert mfma > 100 and touching >= 512
     assert outside == 0, f"{outside} compiler-generated instructions touch AGPRs"
     assert scratch == 0, f"{scratch} scratch (spill) instructions in the training kernel"
+    # k_reni_train_bf16<128, false>: the frozen-decoder instance has no weight-gradient accumulators at all
+    mfma, touching, outside, scratch = _train_kernel_counts(text, "_ZN4reni17k_reni_train_bf16ILi128ELb0EEE")
+    assert mfma > 50 and touching == 0 and scratch == 0
 
 
 def test_mfma_results_are_never_read_before_their_write_back():
