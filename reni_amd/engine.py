@@ -42,13 +42,16 @@ class TrainEngine:
             need_dw=self.train_decoder, need_dz=True)
         self.t += 1
         inv_w = 1.0 / self.world
-        if self.train_decoder:
-            if self.world > 1:
-                torch.distributed.all_reduce(dparams, op=torch.distributed.ReduceOp.SUM)
-            ops.adam_step(self.flat, dparams, self.m_dec, self.v_dec, self.t, self.lr, grad_scale=inv_w)
+        work = None
+        if self.train_decoder and self.world > 1:  # the one collective of the step; the latent update runs beside it
+            work = torch.distributed.all_reduce(dparams, op=torch.distributed.ReduceOp.SUM, async_op=True)
         # dense Adam over the whole (owned) latent table, as the reference does (rows outside the
         # batch have zero gradient but still move by momentum -- SURVEY.md Appendix B9)
         self.g_lat.zero_()
         self.g_lat.index_add_(0, idx, dZ)
         ops.adam_step(self.latent.data, self.g_lat, self.m_lat, self.v_lat, self.t, self.lr, grad_scale=inv_w)
+        if self.train_decoder:
+            if work is not None:
+                work.wait()
+            ops.adam_step(self.flat, dparams, self.m_dec, self.v_dec, self.t, self.lr, grad_scale=inv_w)
         return terms
