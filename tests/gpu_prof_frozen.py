@@ -1,0 +1,19 @@
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+from reni_amd.models import RENIAutoDecoder
+from reni_amd.utils import get_directions, get_sineweight
+dev = torch.device("cuda:0")
+D = get_directions(256).to(dev); S = get_sineweight(256).to(dev); P = D.shape[1]
+B = 32
+T = (torch.rand(B, P, 3, device=dev) * 2 - 1)
+idx = torch.arange(B, device=dev)
+m = RENIAutoDecoder(B, 36, "SO2", 128, 5, 3, True, "tanh", 30, 30, True)
+with torch.no_grad():
+    m.Z.normal_()
+m.set_compute_dtype("bf16").to(dev)
+for _ in range(6):
+    m.zero_grad(set_to_none=True)
+    t = m.fused_loss(m.Z[idx], D, T, S)
+    t[0].backward()
+torch.cuda.synchronize()
