@@ -75,7 +75,8 @@ struct PrepArgs {
   const float* b0;
   float* xconst;  // [B][F_in]
   float* A;       // [B][H][8]
-  char* afrag;    // optional [B][H/32][64 lanes][16 B]: A_b as split-bf16 MFMA A operands (persistent training kernel)
+  char* afrag;    // optional [B][H/32][64 lanes][16 B]: afrag_scale * A_b as split-bf16 MFMA A operands (persistent kernels)
+  float afrag_scale;  // omega_first / 2 pi: the persistent kernels' layer-0 MFMA then yields the sine argument in revolutions
   int eq, nd, F_in, H;
 };
 
