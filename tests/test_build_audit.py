@@ -59,13 +59,16 @@ def _train_kernel_counts(text, mangled_prefix):
 def test_training_kernel_agprs_only_in_hand_written_asm():
     text = _isa("core")
     # k_reni_train_bf16<128, true>: the training instance owns the AGPRs by hand
-    mfma, touching, outside, scratch = _train_kernel_counts(text, "_ZN4reni17k_reni_train_bf16ILi128ELb1EEE")
+    mfma, touching, outside, scratch = _train_kernel_counts(text, "_ZN4reni17k_reni_train_bf16ILi128ELb1ELb0EEE")
     assert mfma > 100 and touching >= 512
     assert outside == 0, f"{outside} compiler-generated instructions touch AGPRs"
     assert scratch == 0, f"{scratch} scratch (spill) instructions in the training kernel"
     # k_reni_train_bf16<128, false>: the frozen-decoder instance has no weight-gradient accumulators at all
-    mfma, touching, outside, scratch = _train_kernel_counts(text, "_ZN4reni17k_reni_train_bf16ILi128ELb0EEE")
+    mfma, touching, outside, scratch = _train_kernel_counts(text, "_ZN4reni17k_reni_train_bf16ILi128ELb0ELb0EEE")
     assert mfma > 50 and touching == 0 and scratch == 0
+    # k_reni_train_bf16<128, false, true>: the forward-only statistics instance
+    mfma, touching, outside, scratch = _train_kernel_counts(text, "_ZN4reni17k_reni_train_bf16ILi128ELb0ELb1EEE")
+    assert mfma > 20 and touching == 0 and scratch == 0
 
 
 def test_mfma_results_are_never_read_before_their_write_back():
