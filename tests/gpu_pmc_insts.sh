@@ -5,5 +5,6 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VM
   tag=$(echo $grp | tr ' ' '_' | cut -c1-60)
   timeout 300 rocprofv3 --pmc $grp --kernel-trace -d gpurun_out/pmc_g/$tag -o p -- python3 bench.py --steps 3 --warmup 1 > gpurun_out/pmc_g/$tag.log 2>&1
   python3 profiles/summarize_pmc.py gpurun_out/pmc_g/$tag/p_results.db 2>&1 | grep -i "train_bf16\|dw1\|^##" >> gpurun_out/pmc_g/summary.md
+  rm -rf gpurun_out/pmc_g/$tag
 done
 cat gpurun_out/pmc_g/summary.md
