@@ -174,6 +174,27 @@ def test_cosine_loss_on_the_persistent_kernels(dev, L):
                 assert O.rel_l2(gp[k].numpy(), ref["grads"][k].numpy()) <= t, k
 
 
+@pytest.mark.parametrize("need_dw", [False, True])
+def test_generic_kernels_when_the_persistent_ones_are_disabled(dev, monkeypatch, need_dw):
+    """H = 128, L <= 5 in bf16 is served by the persistent kernels (training, frozen, forward-only instances); the generic
+    chain + operand-stream path behind them (RENI_NO_PERSIST=1; also what L > 5 and FiLM use) must stay in parity too."""
+    monkeypatch.setenv("RENI_NO_PERSIST", "1")
+    spec = O.DecoderSpec(36, "SO2", 128, 5, 3, True, "tanh")
+    params, Z, D, W, T = random_problem(spec, 3, 333, seed=11)
+    plan = make_plan(spec, "bf16")
+    fp = flat_params(spec, params).to(dev)
+    ref = O.fwd_loss_bwd(spec, params, Z, D.expand(3, -1, 3), T, W.expand(3, -1, 3), need_dw=need_dw)
+    out = plan.forward(Z.to(dev), D.to(dev), fp)
+    assert float((out.cpu() - ref["out"]).abs().max()) <= TOL["bf16"]["out"]
+    lt, dZ, dp, _ = plan.forward_loss_backward(Z.to(dev), D.to(dev), fp, T.to(dev), W.to(dev), need_dw=need_dw)
+    assert abs(float(lt[0]) - ref["loss_terms"][0]) <= TOL["bf16"]["loss"] * abs(ref["loss_terms"][0])
+    assert O.rel_l2(dZ.cpu().numpy(), ref["dZ"].numpy()) <= TOL["bf16"]["grad"]
+    if need_dw:
+        gp = unflatten(spec, dp.cpu())
+        for k in gp:
+            assert O.rel_l2(gp[k].numpy(), ref["grads"][k].numpy()) <= TOL["bf16"]["grad"], k
+
+
 def test_strided_channel_planar_target(dev):
     """targets arrive as the permute+view of [B,3,H,W] images (RENI_module.py:83-84), uncopied."""
     spec = O.DecoderSpec(9, "SO2", 64, 1, 3, True, "tanh")
