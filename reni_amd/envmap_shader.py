@@ -186,26 +186,26 @@ class GBufferRenderer(nn.Module):
 
 
 def build_renderer(obj_path, obj_rotation, img_size, kd, device):
-    """Reference :177-217: load the OBJ, rasterise it once with pytorch3d and shade with the environment map.
-    The rasteriser is pytorch3d's; without the package use ``GBufferRenderer`` with a stored G-buffer."""
+    """Same signature and return value as the reference's ``build_renderer`` (:177-217): ``(renderer, R, T, mesh)`` with
+    ``renderer(meshes_world=mesh, R=R, T=T, envmap=...)`` -> ``(render, pixel_normals)``.  pytorch3d does the mesh
+    loading and the one rasterisation; the shading is this module's HIP path.  Without pytorch3d use
+    ``GBufferRenderer`` with a stored G-buffer."""
     try:
+        import pytorch3d.renderer as p3r
         from pytorch3d.io import load_obj
-        from pytorch3d.renderer import (FoVPerspectiveCameras, Materials, MeshRasterizer, MeshRenderer,
-                                        RasterizationSettings, TexturesVertex, look_at_view_transform)
         from pytorch3d.structures import Meshes
         from pytorch3d.transforms import RotateAxisAngle
-    except ImportError as e:  # pragma: no cover - pytorch3d is absent from this image
+    except ImportError as e:  # pytorch3d is absent from this image
         raise ImportError("build_renderer needs pytorch3d (mesh loading and rasterisation); with a stored G-buffer use "
                           "reni_amd.envmap_shader.GBufferRenderer instead") from e
-    verts, faces_idx, _ = load_obj(obj_path, load_textures=False, device=device)  # pragma: no cover
-    faces = faces_idx.verts_idx
-    verts = RotateAxisAngle(obj_rotation, "Y", device=device).transform_points(verts)
-    verts_rgb = torch.ones_like(verts)[None]
-    mesh = Meshes(verts=[verts.to(device)], faces=[faces.to(device)], textures=TexturesVertex(verts_features=verts_rgb.to(device)))
-    cameras = FoVPerspectiveCameras(device=device)
-    raster_settings = RasterizationSettings(image_size=img_size, blur_radius=0.0, faces_per_pixel=1, perspective_correct=False)
-    renderer = MeshRenderer(rasterizer=MeshRasterizer(cameras=cameras, raster_settings=raster_settings),
-                            shader=BlinnPhongShaderEnvMap(device=device, cameras=cameras, envmap=None,
-                                                          materials=Materials(shininess=500), kd=kd, ks=1.0 - kd))
-    R, T = look_at_view_transform(2.0, 0.0, 0.0, degrees=True, device=device)
-    return renderer, R, T, mesh
+    # pragma: no cover -- everything below needs pytorch3d
+    verts, faces_idx, _ = load_obj(obj_path, load_textures=False, device=device)
+    verts = RotateAxisAngle(obj_rotation, "Y", device=device).transform_points(verts).to(device)
+    white = p3r.TexturesVertex(verts_features=torch.ones(1, verts.shape[0], 3, device=device))
+    mesh = Meshes(verts=[verts], faces=[faces_idx.verts_idx.to(device)], textures=white)
+    cameras = p3r.FoVPerspectiveCameras(device=device)
+    shader = BlinnPhongShaderEnvMap(device=device, cameras=cameras, materials=p3r.Materials(shininess=500), kd=kd, ks=1.0 - kd)
+    raster = p3r.MeshRasterizer(cameras=cameras, raster_settings=p3r.RasterizationSettings(
+        image_size=img_size, blur_radius=0.0, faces_per_pixel=1, perspective_correct=False))
+    R, T = p3r.look_at_view_transform(2.0, 0.0, 0.0, degrees=True, device=device)
+    return p3r.MeshRenderer(rasterizer=raster, shader=shader), R, T, mesh
