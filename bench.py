@@ -104,12 +104,13 @@ def main():
     sineweight = get_sineweight(W_IMG).to(dev)
     P = directions.shape[1]
 
+    idx_all = torch.arange(n_local, device=dev)  # (the loader's indices: resident like the images)
+
     def batch(step):
         """B consecutive owned images; targets are the reference's permute+view of [B,3,H,W]
         (RENI_module.py:83-84): a channel-planar strided view, never copied."""
         start = (step * B) % (n_local - B + 1)
-        idx = torch.arange(start, start + B, device=dev)
-        return idx, imgs[start:start + B].permute(0, 2, 3, 1).view(B, P, 3)
+        return idx_all[start:start + B], imgs[start:start + B].permute(0, 2, 3, 1).view(B, P, 3)
 
     def barrier():
         if world > 1:

@@ -190,6 +190,14 @@ int reni_film_model_backward(const reni_plan* plan, int64_t B, int64_t P, const 
 int reni_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
                    float b2, float eps, int64_t step, float grad_scale, void* stream);
 
+/* The same Adam step over a table p [n_rows][row_len] whose gradient is given for the B rows idx[0..B) only
+ * (g_rows [B][row_len], idx int64 on the device; repeated indices accumulate).  All other rows have gradient zero and
+ * still move by their momentum: the dense torch.optim.Adam over the whole latent table that the reference runs
+ * (RENI_module.py:178-192 puts model.Z / model.mu, all N rows, into the optimiser; a batch touches B of them). */
+int reni_adam_rows_step(float* p, const float* g_rows, const int64_t* idx, int64_t B, int64_t row_len, float* m, float* v,
+                        int64_t n_rows, float lr, float b1, float b2, float eps, int64_t step, float grad_scale,
+                        void* stream);
+
 /* Self-test of the MFMA fragment layouts the kernels rely on; out (host pointer) receives the
  * number of mismatching elements per probe (0 = layout as assumed). */
 int reni_selftest_layouts(int32_t* out_host_mismatch, int32_t n_probes);

@@ -25,7 +25,7 @@ COND_CONCAT, COND_FILM = 0, 1
 EXPORTS = (
     "reni_last_error", "reni_plan_create", "reni_plan_destroy", "reni_param_count", "reni_in_features",
     "reni_workspace_bytes", "reni_forward", "reni_forward_loss_backward", "reni_backward",
-    "reni_adam_step", "reni_selftest_layouts", "reni_launch_info", "reni_profile_enable", "reni_profile_read", "reni_probe_tr",
+    "reni_adam_step", "reni_adam_rows_step", "reni_selftest_layouts", "reni_launch_info", "reni_profile_enable", "reni_profile_read", "reni_probe_tr",
     "reni_film_forward", "reni_film_forward_loss_backward", "reni_film_backward",
     "reni_film_map_param_count", "reni_film_model_forward", "reni_film_model_forward_loss_backward",
     "reni_film_model_backward",
@@ -108,6 +108,9 @@ def load():
     lib.reni_adam_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                    c_float, c_int64, c_float, c_void_p]
     lib.reni_adam_step.restype = c_int32
+    lib.reni_adam_rows_step.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_float,
+                                        c_float, c_float, c_float, c_int64, c_float, c_void_p]
+    lib.reni_adam_rows_step.restype = c_int32
     lib.reni_selftest_layouts.argtypes = [POINTER(c_int32), c_int32]
     lib.reni_selftest_layouts.restype = c_int32
     lib.reni_launch_info.argtypes = [c_void_p, c_int64, c_int64, POINTER(c_int32)]

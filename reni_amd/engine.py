@@ -29,7 +29,6 @@ class TrainEngine:
         self.v_dec = torch.zeros_like(self.flat)
         self.m_lat = torch.zeros_like(self.latent.data)
         self.v_lat = torch.zeros_like(self.latent.data)
-        self.g_lat = torch.zeros_like(self.latent.data)
         self.t = 0
         self.world = rdist.world_size()
 
@@ -47,9 +46,7 @@ class TrainEngine:
             work = torch.distributed.all_reduce(dparams, op=torch.distributed.ReduceOp.SUM, async_op=True)
         # dense Adam over the whole (owned) latent table, as the reference does (rows outside the
         # batch have zero gradient but still move by momentum -- SURVEY.md Appendix B9)
-        self.g_lat.zero_()
-        self.g_lat.index_add_(0, idx, dZ)
-        ops.adam_step(self.latent.data, self.g_lat, self.m_lat, self.v_lat, self.t, self.lr, grad_scale=inv_w)
+        ops.adam_rows_step(self.latent.data, dZ, idx, self.m_lat, self.v_lat, self.t, self.lr, grad_scale=inv_w)
         if self.train_decoder:
             if work is not None:
                 work.wait()

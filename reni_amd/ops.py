@@ -317,6 +317,22 @@ def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor
                                   float(betas[0]), float(betas[1]), float(eps), int(step), float(grad_scale), stream))
 
 
+def adam_rows_step(table: torch.Tensor, g_rows: torch.Tensor, idx: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int,
+                   lr: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
+    """In-place dense Adam step on table [N, ...] with the gradient g_rows [B, ...] of rows idx (reni_adam_rows_step)."""
+    _require_cuda(table, g_rows, idx, m, v)
+    lib = _lib.load()
+    assert table.is_contiguous() and g_rows.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+    idx = idx.to(torch.int64).contiguous()
+    n_rows = table.shape[0]
+    row_len = table.numel() // max(n_rows, 1)
+    assert g_rows.numel() == idx.numel() * row_len
+    stream = torch.cuda.current_stream(table.device).cuda_stream
+    _lib.check(lib.reni_adam_rows_step(table.data_ptr(), g_rows.data_ptr(), idx.data_ptr(), idx.numel(), row_len, m.data_ptr(),
+                                       v.data_ptr(), n_rows, float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
+                                       float(grad_scale), stream))
+
+
 def selftest_layouts():
     lib = _lib.load()
     out = (ctypes.c_int32 * 2)()

@@ -242,3 +242,25 @@ def test_multires_curriculum_and_exponential_lr(dev):
             lrs.append(o.param_groups[0]["lr"])
             sched.step()
         np.testing.assert_allclose(lrs, [1e-2 * gamma ** e for e in range(4)], rtol=1e-6)
+
+
+def test_adam_rows_step_is_dense_adam_over_the_table(dev):
+    """reni_adam_rows_step == torch.optim.Adam over the WHOLE table with a gradient that is zero outside the batch's rows
+    (rows absent from a batch still move by momentum; repeated indices accumulate like index_add_)."""
+    from reni_amd import ops
+    g = torch.Generator().manual_seed(3)
+    N, row = 37, 27
+    table = torch.randn(N, 9, 3, generator=g)
+    ref = table.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-2)
+    t = table.clone().to(dev)
+    m, v = torch.zeros_like(t), torch.zeros_like(t)
+    for step, idx in enumerate(([3, 5, 20], [5, 5, 36, 0], [1]), start=1):
+        idx = torch.tensor(idx)
+        gr = torch.randn(len(idx), 9, 3, generator=g)
+        dense = torch.zeros(N, 9, 3).index_add_(0, idx, gr)
+        opt.zero_grad()
+        ref.grad = dense * 0.5
+        opt.step()
+        ops.adam_rows_step(t, gr.to(dev), idx.to(dev), m, v, step, 1e-2, grad_scale=0.5)
+    assert float((t.cpu() - ref.detach()).abs().max()) <= 2e-6
