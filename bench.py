@@ -1,25 +1,34 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's headline metric on the fused HIP path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Metric  : directional samples / second, forward + backward (one sample = one (image, direction)
-          pair through encoding -> SIREN -> loss -> gradients).
-Workload: BASELINE config 2 -- a 615-image training set, 128x256 equirect (P = 32768), ND = 36,
-          5x128 SIREN, SO2, tanh, AutoDecoder, RENITrainLoss, bf16 MFMA; per-GPU batch = 64 images
-          (the largest power of two that 8 ranks can each draw from their 76-77 owned images).  Synthetic images / random-init weights (seed 42).
-Step    : ONE full training iteration = fused forward+loss+backward (decoder and latent gradients)
-          -> [N > 1: one RCCL all-reduce of the flat decoder gradient] -> Adam on decoder + latents.
+Metric  : directional samples / second (one sample = one (image, direction) pair through encoding -> SIREN ->
+          loss -> gradients).
+Workload: --config c2 (default, the configuration BASELINE.json's metric is quoted on): a 615-image training set,
+          128x256 equirect (P = 32768), ND = 36, 5x128 SIREN, SO2, tanh, AutoDecoder, RENITrainLoss, bf16 MFMA;
+          per-GPU batch = 64 images (the largest power of two that 8 ranks can each draw from their 76-77 owned images);
+          one step = fused forward+loss+backward (decoder and latent gradients) -> [N > 1: ONE RCCL all-reduce of the
+          flat decoder gradient] -> Adam on decoder + latents.
+          --config c4 (BASELINE config 4): test-time latent optimisation -- 21 held-out maps, frozen decoder, masked
+          RENITestLoss(1e-7, 1e-4) with the cosine term, per-image latent Adam (lr 0.1); one step = statistics pass +
+          latent forward/backward + Adam on the latent rows.  No collective (every rank: its own 21 maps).
+          --config c5 (BASELINE config 5): fp32 inference at 512x1024 directions, ND = 49, 4 images per step.
+          Synthetic images / random-init weights (seed 42).
 Scaling : weak (per-GPU batch fixed; images and their latent rows sharded round-robin over ranks).
+Launch  : with WORLD_SIZE / RANK in the environment (torchrun) this process is one rank.  Without them and --gpus N > 1
+          it spawns N rank processes itself -- BEFORE anything touches the GPU -- and returns the worst exit code.
 
-Rank 0 prints ONE JSON line (contract in the task statement) including `roofline` (dominant kernel,
-timed live with HIP events on its own stream) and, at N = 1, `cpu_baseline` (the CPU oracle's
-reference-shaped step timed on this box's host cores on a bounded sample).
+Rank 0 prints ONE JSON line (contract in the task statement) including `roofline` (dominant kernel, timed live with HIP
+events on its own stream) and, at N = 1, `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded
+sample: B = 1 and B = 4 images, 3 warm-up + 10 timed steps each, reference-shaped and factored -- SURVEY.md 8d).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,10 +36,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-FLOP_PER_SAMPLE = 522784       # fwd+bwd, factored form (SURVEY.md 8d / BASELINE.md section 4)
+# algorithmic work per sample, factored form (SURVEY.md 8d / BASELINE.md section 4)
+FLOP_TRAIN, FLOP_FROZEN, FLOP_FWD_ND49 = 522784, 348448, 177860
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # {"<kernel>": {"hbm_bytes_per_launch": .., "src_sha256": ..}}
 
 
 def parse():
@@ -38,41 +47,97 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step (<= 615/8 so 8 ranks can own them)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"])
+    ap.add_argument("--batch", type=int, default=None,
+                    help="images per GPU per step (c2: 64, <= 615/8 so that 8 ranks can own them; c4: 21; c5: 4)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32"], help="c2 / c4: bf16, c5: f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=10)
     return ap.parse_args()
 
 
+def spawn_ranks(n):
+    """python bench.py --gpus N without a launcher: start N rank processes (children of this one, which has not
+    touched the GPU and never will) with the environment torchrun would give them; rank 0's stdout is ours."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def _median_step_s(fn, warm, n):
+    ts = []
+    for i in range(warm + n):
+        t0 = time.perf_counter()
+        fn()
+        if i >= warm:
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
 def cpu_baseline(n_steps):
-    """Reference-shaped CPU step (oracle: materialised encoding, linear+sin, autograd, WeightedMSE) on
-    the same workload shape, B = 1 image per step; median of n_steps after 2 warm-ups."""
+    """the CPU oracle on the config-2 shape, fp32, all host threads, B = 1 and B = 4 images per step,
+    3 warm-up + n_steps timed forward+loss+backward steps each (median), in two forms: "port" = reference-shaped
+    (materialised 1370-column encoding, linear + sin, autograd: the op sequence of src/models/RENI.py:31-53,86-87) and
+    "factored" (the algebra the kernels implement, per-image constants folded into an affine map).  `value` is the
+    reference-shaped figure at the better of the two batch sizes."""
+    import torch
     from oracle import reni_oracle as O
     spec = O.DecoderSpec(36, "SO2", 128, 5, 3, True, "tanh")
     g = torch.Generator().manual_seed(42)
     params = O.init_params(spec, g)
-    Z = torch.randn(1, 36, 3, generator=g)
     D = O.get_directions(256); S = O.get_sineweight(256)
-    T = O.synthetic_images([0], 128, 256).permute(0, 2, 3, 1).reshape(1, -1, 3)
-    times = []
-    for i in range(n_steps + 2):
-        t0 = time.perf_counter()
-        O.fwd_loss_bwd(spec, params, Z, D, T, S)
-        if i >= 2:
-            times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": D.shape[1] / med, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_steps} fwd+loss+bwd steps of 1 image x 32768 directions (config-2 shape, fp32, "
-                      f"reference-shaped: materialised 1370-column encoding + autograd), median"}
+    P = D.shape[1]
+    res = {}
+    for B in (1, 4):
+        Z = torch.randn(B, 36, 3, generator=g)
+        T = O.synthetic_images(list(range(B)), 128, 256).permute(0, 2, 3, 1).reshape(B, -1, 3)
+        Db, Sb = D.expand(B, -1, 3), S.expand(B, -1, 3)
+        res[f"port_b{B}"] = B * P / _median_step_s(lambda: O.fwd_loss_bwd(spec, params, Z, Db, T, Sb), 3, n_steps)
+        res[f"factored_b{B}"] = B * P / _median_step_s(lambda: O.factored_torch_fwd_loss_bwd(spec, params, Z, D, T, Sb), 3, n_steps)
+    return {"value": max(res["port_b1"], res["port_b4"]), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "port_b1": res["port_b1"], "port_b4": res["port_b4"],
+            "factored": max(res["factored_b1"], res["factored_b4"]), "factored_b1": res["factored_b1"], "factored_b4": res["factored_b4"],
+            "sample": f"config-2 shape (128x256 directions, ND=36, 5x128, fp32), B=1 and B=4 images per step, 3 warm-up + "
+                      f"{n_steps} timed fwd+loss+bwd steps each, median; port = reference-shaped (materialised 1370-column "
+                      f"encoding + autograd), factored = per-image affine first layer + autograd"}
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch from the PMC passes (tests/gpu_profile_round.sh), valid only for the kernel sources it
+    was measured on: the file carries the sha256 of reni_device.inc, and a stale entry reads as null."""
+    import hashlib
+    try:
+        rec = json.load(open(PMC_TRAFFIC)).get(kernel)
+        src = hashlib.sha256(open(os.path.join(ROOT, "reni_amd", "csrc", "reni_device.inc"), "rb").read()).hexdigest()
+        if rec and rec.get("src_sha256") == src:
+            return rec.get("hbm_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        pass
+    return None
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
+    import torch
     from reni_amd import dist as rdist
     rank, world, local = rdist.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -83,34 +148,61 @@ def main():
     from reni_amd.models import RENIAutoDecoder
     from reni_amd.utils import get_directions, get_sineweight
 
-    N_IMAGES, H_IMG, W_IMG, ND = 615, 128, 256, 36
-    B = args.batch
-    owned = rdist.owned_indices(N_IMAGES, rank, world)
+    cfg = args.config
+    dtype = args.dtype or ("f32" if cfg == "c5" else "bf16")
     torch.manual_seed(42)
-    model = RENIAutoDecoder(N_IMAGES, ND, "SO2", 128, 5, 3, True, "tanh", 30.0, 30.0, False)
-    model.set_compute_dtype(args.dtype)
+    if cfg == "c2":
+        N_IMAGES, H_IMG, W_IMG, ND, B = 615, 128, 256, 36, args.batch or 64
+        owned = rdist.owned_indices(N_IMAGES, rank, world)
+        model = RENIAutoDecoder(N_IMAGES, ND, "SO2", 128, 5, 3, True, "tanh", 30.0, 30.0, False)
+    elif cfg == "c4":
+        N_IMAGES, H_IMG, W_IMG, ND, B = 21, 128, 256, 36, args.batch or 21
+        owned = list(range(N_IMAGES))  # every rank optimises its own 21 held-out maps (no shared state, no collective)
+        model = RENIAutoDecoder(N_IMAGES, ND, "SO2", 128, 5, 3, True, "tanh", 30.0, 30.0, True)
+        with torch.no_grad():
+            model.Z.normal_()  # (fixed_decoder starts the latents at zero; any start costs the same)
+    else:
+        N_IMAGES, H_IMG, W_IMG, ND, B = 4, 512, 1024, 49, args.batch or 4
+        owned = list(range(N_IMAGES))
+        model = RENIAutoDecoder(N_IMAGES, ND, "SO2", 128, 5, 3, True, "tanh", 30.0, 30.0, True)
+        with torch.no_grad():
+            model.Z.normal_()
+    model.set_compute_dtype(dtype)
     with torch.no_grad():  # this rank keeps only the latent rows of the images it owns
-        model.Z = torch.nn.Parameter(model.Z[owned].clone())
+        model.Z = torch.nn.Parameter(model.Z[owned].clone(), requires_grad=model.Z.requires_grad)
     model.to(dev)
-    rdist.broadcast_(model._flat_params(), 0)
-    eng = TrainEngine(model, lr=1e-5)
-
-    # this rank's shard of the synthetic training set, resident in HBM before the timed region
-    ds = SyntheticEnvMapDataset(N_IMAGES, H_IMG, W_IMG)
+    if world > 1:
+        rdist.broadcast_(model._flat_params(), 0)
     n_local = len(owned)
     assert n_local >= B, f"per-GPU batch {B} exceeds the {n_local} images this rank owns"
-    imgs = torch.stack([ds.make(i) for i in owned]).to(dev)      # [n_local,3,H,W], ~0.39 MB per image
     directions = get_directions(W_IMG).to(dev)
     sineweight = get_sineweight(W_IMG).to(dev)
     P = directions.shape[1]
-
     idx_all = torch.arange(n_local, device=dev)  # (the loader's indices: resident like the images)
 
-    def batch(step):
-        """B consecutive owned images; targets are the reference's permute+view of [B,3,H,W]
-        (RENI_module.py:83-84): a channel-planar strided view, never copied."""
-        start = (step * B) % (n_local - B + 1)
-        return idx_all[start:start + B], imgs[start:start + B].permute(0, 2, 3, 1).view(B, P, 3)
+    if cfg in ("c2", "c4"):
+        # this rank's shard of the synthetic set, resident in HBM before the timed region
+        ds = SyntheticEnvMapDataset(N_IMAGES, H_IMG, W_IMG)
+        imgs = torch.stack([ds.make(i) for i in owned]).to(dev)      # [n_local,3,H,W], ~0.39 MB per image
+        if cfg == "c2":
+            eng = TrainEngine(model, lr=1e-5)
+            weight = sineweight
+        else:
+            # inpainting mask of the notebook's kind (examples.ipynb cell 4, Mask-3: 18.8 % of the pixels kept): a
+            # synthetic binary column mask with the same kept fraction, multiplied into the sine weight (RENI_module.py:92-94)
+            keep = (torch.arange(W_IMG, device=dev) < int(0.188 * W_IMG)).float().view(1, 1, W_IMG, 1).expand(1, H_IMG, W_IMG, 3)
+            weight = sineweight * keep.reshape(1, P, 3)
+            eng = TrainEngine(model, lr=1e-1, loss_kind="test", alpha=1e-7, beta=1e-4)
+
+        def step(s):
+            """B consecutive owned images; targets are the reference's permute+view of [B,3,H,W]
+            (RENI_module.py:83-84): a channel-planar strided view, never copied."""
+            start = (s * B) % (n_local - B + 1)
+            return eng.step(idx_all[start:start + B], imgs[start:start + B].permute(0, 2, 3, 1).view(B, P, 3), weight, directions)
+    else:
+        def step(s):
+            with torch.no_grad():
+                return model(idx_all[:B], directions)
 
     def barrier():
         if world > 1:
@@ -120,56 +212,63 @@ def main():
     if world > 1:  # create the RCCL communicator outside the timed region even with --warmup 0
         torch.distributed.all_reduce(torch.zeros(1, device=dev))
     for s in range(args.warmup):
-        idx, tgt = batch(s)
-        eng.step(idx, tgt, sineweight, directions)
+        step(s)
     barrier()
     ops.profile_enable(True)
-    ops.profile_read(reset=True)
+    ops.profile_read(reset=True, kind=ops.PROF_ALL)
     t0 = time.perf_counter()
     last = None
     for s in range(args.steps):
-        idx, tgt = batch(args.warmup + s)
-        last = eng.step(idx, tgt, sineweight, directions)
+        last = step(args.warmup + s)
     barrier()
     dt = time.perf_counter() - t0
-    kern_ms, kern_n = ops.profile_read(reset=True)
+    kind = ops.PROF_FWD if cfg == "c5" else ops.PROF_FWD_BWD
+    kern_ms, kern_n = ops.profile_read(reset=False, kind=kind)
+    stats_ms, stats_n = ops.profile_read(reset=True, kind=ops.PROF_STATS)
     ops.profile_enable(False)
-    loss = float(last[0])
-    assert loss == loss and abs(loss) < 1e6, f"non-finite loss {loss}"
+    check = float(last[0]) if cfg != "c5" else float(last.abs().max())
+    assert check == check and abs(check) < 1e6, f"non-finite result {check}"
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax)
-    samples_per_step = world * B * P
-    value = samples_per_step * args.steps / dt
+    value = world * B * P * args.steps / dt
 
     if rank == 0:
         kavg_ms = kern_ms / max(kern_n, 1)
-        achieved = B * P * FLOP_PER_SAMPLE / (kavg_ms * 1e-3) / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
+        if cfg == "c2":
+            flop = FLOP_TRAIN
+            kernel = "k_reni_train_bf16<128,true>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD>"
+            workload = ("BASELINE config 2: 615-image set, 128x256 equirect, ND=36, 5x128 SIREN, SO2, tanh, AutoDecoder, "
+                        "RENITrainLoss; full training step (fwd+loss+bwd, grad all-reduce, Adam)")
+        elif cfg == "c4":
+            flop = FLOP_FROZEN
+            kernel = "k_reni_train_bf16<128,false>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD>"
+            workload = ("BASELINE config 4: test-time latent optimisation, 21 held-out maps, 128x256 equirect, ND=36, 5x128 SIREN, "
+                        "frozen decoder, masked (18.8 % kept) RENITestLoss(1e-7,1e-4) with the cosine term, per-image latent "
+                        "Adam lr 0.1; full step (statistics pass + latent fwd/bwd + Adam)")
+        else:
+            flop = FLOP_FWD_ND49
+            kernel = "k_reni_main<f32,H=128,FWD>" if dtype == "f32" else "k_reni_train_bf16<128,false,true>"
+            workload = "BASELINE config 5: inference, 512x1024 directions, ND=49, 5x128 SIREN, SO2, 4 images per step"
+        achieved = B * P * flop / (kavg_ms * 1e-3) / 1e12
         line = {
-            "metric": "directional-samples/sec (fwd+bwd), 128x256 equirect, ND=36 latent",
+            "metric": "directional-samples/sec (fwd+bwd), 128x256 equirect, ND=36 latent" if cfg != "c5"
+                      else "directional-samples/sec (fwd), 512x1024 equirect, ND=49 latent",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: 615-image set, 128x256 equirect, ND=36, 5x128 SIREN, SO2, "
-                                   "tanh, AutoDecoder, RENITrainLoss; full training step (fwd+loss+bwd, grad "
-                                   "all-reduce, Adam)", "images_per_gpu_per_step": B,
-                       "global_batch_images": world * B, "directions_per_image": P,
-                       "parallelism": f"dp{world}", "loss_last_step": loss},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": traffic,
-                         "kernel": "k_reni_train_bf16<128,true>" if args.dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD>",
-                         "kernel_avg_ms": kavg_ms,
-                         "kernel_launches": kern_n, "flop_per_sample": FLOP_PER_SAMPLE},
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "n_ranks_seen": torch.distributed.get_world_size() if world > 1 else 1,
+            "dist_backend": torch.distributed.get_backend() if world > 1 else None,
+            "config": {"workload": workload, "images_per_gpu_per_step": B, "global_batch_images": world * B,
+                       "directions_per_image": P, "parallelism": f"dp{world}", "result_check": check},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_TFLOPS[dtype], "traffic": pmc_traffic(kernel), "kernel": kernel,
+                         "kernel_avg_ms": kavg_ms, "kernel_launches": kern_n, "flop_per_sample": flop},
         }
+        if stats_n:
+            line["roofline"]["stats_pass_avg_ms"] = stats_ms / stats_n
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_steps)
         print(json.dumps(line), flush=True)

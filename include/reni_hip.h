@@ -207,6 +207,9 @@ int reni_selftest_layouts(int32_t* out_host_mismatch, int32_t n_probes);
  * returns their summed duration and count since the last reset.  Used by bench.py for `roofline`. */
 int reni_profile_enable(int32_t on);
 int reni_profile_read(double* total_ms, int64_t* launches, int32_t reset);
+/* The same, restricted to one kind of launch: 0 fused forward+loss+backward (what reni_profile_read returns),
+ * 1 the statistics pass of RENITestLoss's cosine term, 2 plain inference (reni_forward), -1 all of them. */
+int reni_profile_read_kind(int32_t kind, double* total_ms, int64_t* launches, int32_t reset);
 
 /* Diagnostic probe of the LDS transpose-read instruction (ds_read_b64_tr_b16): LDS holds u16 element i = i;
  * lane l reads at byte address 8*l (mode 0) or lane_addr_host[l] (mode 1); out_host[4*l + e] = element e. */
@@ -237,6 +240,29 @@ int reni_envmap_shade_backward(int64_t B, int64_t NP, int64_t J, const float* no
                                float cam_y, float cam_z, const float* light_dirs, int64_t dirs_batch_stride,
                                const float* dcolors, float shininess, float kd, float ks, float* dlight_colors, void* ws,
                                size_t ws_bytes, void* stream);
+
+/* ---- HDR image epilogue / prologue ------------------------------------------------
+ * reni_unnormalise_srgb replaces, on the device and in one call, the reference's viewing chain
+ *   UnMinMaxNormlise(minmax)   src/utils/custom_transforms.py:14-21   y = exp(0.5 (x + 1)(m1 - m0) + m0)
+ *   sRGB                       src/utils/utils.py:30-42               y / q_b, clamp to [0,1], sRGB transfer curve, where
+ *                              q_b = the nested 0.98-quantile over channels, then rows, then columns of image b
+ *                              (torch.quantile semantics: rank q (n - 1) in fp32, ATen's lerp between the neighbours)
+ * as the image callbacks apply it to a model output (src/lightning/callbacks.py; RENI_module.py:108 un-normalises in the
+ * FIT_INVERSE step).
+ *   img        : element (b, c, h, w) at img[b*strides[0] + c*strides[1] + h*strides[2] + w*strides[3]] (floats) -- a
+ *                model output [B, H*W, 3] is read in place with strides {3HW, 1, 3W, 3}, a [B,3,H,W] batch with {3HW, HW, W, 1}
+ *   unnormalise: 1 = apply UnMinMaxNormlise(minmax0, minmax1) first, 0 = img is linear already (plain sRGB())
+ *   srgb       : 1 = produce out_srgb [B][3][H][W]; 0 = only the linear image
+ *   out_linear : [B][3][H][W] linear HDR, or NULL when not wanted (then srgb must be 1)
+ *   ws         : reni_image_workspace_bytes(B, H, W) bytes, 256-byte aligned (needed when srgb = 1); H, W <= 4096
+ * reni_minmax_normalise is the forward transform MinMaxNormalise (custom_transforms.py:4-12) over the n elements of one
+ * image: clip to [smallest positive, largest finite value of the image] -> log -> 2 (. - m0) / (m1 - m0) - 1. */
+size_t reni_image_workspace_bytes(int64_t B, int64_t H, int64_t W);
+int reni_unnormalise_srgb(int64_t B, int64_t H, int64_t W, const float* img, const int64_t strides[4], int32_t unnormalise,
+                          double minmax0, double minmax1, int32_t srgb, float* out_srgb, float* out_linear, void* ws,
+                          size_t ws_bytes, void* stream);
+int reni_minmax_normalise(int64_t n, const float* img, double minmax0, double minmax1, float* out, void* ws, size_t ws_bytes,
+                          void* stream);
 
 /* Launch geometry chosen for (B,P): workgroups, threads, dynamic LDS bytes (diagnostics). */
 int reni_launch_info(const reni_plan* plan, int64_t B, int64_t P, int32_t* info4);

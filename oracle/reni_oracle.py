@@ -296,6 +296,50 @@ def fwd_loss_bwd(spec: DecoderSpec, params: Dict[str, torch.Tensor], Z: torch.Te
     }
 
 
+def factored_torch_fwd_loss_bwd(spec: DecoderSpec, params: Dict[str, torch.Tensor], Z: torch.Tensor,
+                                D: torch.Tensor, target: torch.Tensor, weight: torch.Tensor, need_dw: bool = True):
+    """fp32 torch + autograd on the FACTORED algebra (variant B): the per-image constant
+    columns of the reference's concatenated input (RENI.py:27,51,59) are folded into a per-image affine map
+    a0 = A_b (dx, dy, dz, r, 1), so nothing of width F_in is materialised per sample.  Same layers and loss as
+    ``fwd_loss_bwd`` (WeightedMSE); checked against it in tests/test_oracle_golden.py.  This is the "factored" figure
+    of bench.py's cpu_baseline: what a CPU does with the algorithm the HIP kernels implement."""
+    keys = spec.param_keys()
+    Zr = Z.detach().clone().requires_grad_(True)
+    ps = {k: v.detach().clone().requires_grad_(need_dw) for k, v in params.items()}
+    W0, b0 = ps[keys[0]], ps[keys[1]]
+    nd, H = spec.ndims, spec.hidden_features
+    B, P = Zr.shape[0], D.shape[1]
+    Dd = D if D.shape[0] == B else D.expand(B, P, 3)
+    r = torch.sqrt(Dd[..., 0] ** 2 + Dd[..., 2] ** 2)
+    X5 = torch.stack((Dd[..., 0], Dd[..., 1], Dd[..., 2], r, torch.ones_like(r)), -1)  # [B,P,5]
+    if spec.equivariance == "SO2":
+        W_ip, W_G, w_r = W0[:, :nd], W0[:, nd:nd + nd * nd], W0[:, nd + nd * nd]
+        W_zy, w_dy = W0[:, nd + nd * nd + 1:2 * nd + nd * nd + 1], W0[:, 2 * nd + nd * nd + 1]
+        Zxz = Zr[:, :, [0, 2]]
+        U = torch.einsum("hn,bnk->bhk", W_ip, Zxz)  # [B,H,2]
+        G = Zxz @ Zxz.transpose(1, 2)
+        c = G.reshape(B, -1) @ W_G.T + Zr[:, :, 1] @ W_zy.T + b0
+        A = torch.stack((U[..., 0], w_dy.expand(B, H), U[..., 1], w_r.expand(B, H), c), -1)  # [B,H,5]
+    else:
+        W_ip, W_c = W0[:, :nd], W0[:, nd:]
+        U = torch.einsum("hn,bnk->bhk", W_ip, Zr)  # [B,H,3]
+        const = (Zr @ Zr.transpose(1, 2)).reshape(B, -1) if spec.equivariance == "SO3" else Zr.reshape(B, -1)
+        c = const @ W_c.T + b0
+        A = torch.cat((U, torch.zeros(B, H, 1), c.unsqueeze(-1)), -1)
+    h = torch.sin(spec.first_omega_0 * (X5 @ A.transpose(1, 2)))
+    L = spec.hidden_layers
+    for i in range(1, L + 1):
+        h = torch.sin(spec.hidden_omega_0 * torch.nn.functional.linear(h, ps[keys[2 * i]], ps[keys[2 * i + 1]]))
+    y = torch.nn.functional.linear(h, ps[keys[2 * L + 2]], ps[keys[2 * L + 3]])
+    if not spec.last_layer_linear:
+        y = torch.sin(spec.hidden_omega_0 * y)
+    out = torch.tanh(y) if spec.output_activation == "tanh" else torch.exp(y) if spec.output_activation == "exp" else y
+    loss = train_loss(out, target, weight)
+    loss.backward()
+    return {"out": out.detach(), "loss_terms": (float(loss.detach()),) * 2 + (0.0, 0.0), "dZ": Zr.grad.detach(),
+            "grads": {k: v.grad.detach() for k, v in ps.items()} if need_dw else {}}
+
+
 # --------------------------------------------------------------------------------------
 # factored float64 restatement with the hand-derived backward (SURVEY.md Appendix A)
 # --------------------------------------------------------------------------------------

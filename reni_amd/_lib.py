@@ -25,11 +25,12 @@ COND_CONCAT, COND_FILM = 0, 1
 EXPORTS = (
     "reni_last_error", "reni_plan_create", "reni_plan_destroy", "reni_param_count", "reni_in_features",
     "reni_workspace_bytes", "reni_forward", "reni_forward_loss_backward", "reni_backward",
-    "reni_adam_step", "reni_adam_rows_step", "reni_selftest_layouts", "reni_launch_info", "reni_profile_enable", "reni_profile_read", "reni_probe_tr",
+    "reni_adam_step", "reni_adam_rows_step", "reni_selftest_layouts", "reni_launch_info", "reni_profile_enable", "reni_profile_read", "reni_profile_read_kind", "reni_probe_tr",
     "reni_film_forward", "reni_film_forward_loss_backward", "reni_film_backward",
     "reni_film_map_param_count", "reni_film_model_forward", "reni_film_model_forward_loss_backward",
     "reni_film_model_backward",
     "reni_envmap_shade_workspace_bytes", "reni_envmap_shade", "reni_envmap_shade_backward",
+    "reni_image_workspace_bytes", "reni_unnormalise_srgb", "reni_minmax_normalise",
 )
 
 
@@ -119,12 +120,22 @@ def load():
     lib.reni_profile_enable.restype = c_int32
     lib.reni_profile_read.argtypes = [POINTER(ctypes.c_double), POINTER(c_int64), c_int32]
     lib.reni_profile_read.restype = c_int32
+    lib.reni_profile_read_kind.argtypes = [c_int32, POINTER(ctypes.c_double), POINTER(c_int64), c_int32]
+    lib.reni_profile_read_kind.restype = c_int32
     lib.reni_envmap_shade_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]
     lib.reni_envmap_shade_workspace_bytes.restype = c_size_t
     for fn in (lib.reni_envmap_shade, lib.reni_envmap_shade_backward):
         fn.argtypes = [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_int64,
                        c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]
         fn.restype = c_int32
+    lib.reni_image_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]
+    lib.reni_image_workspace_bytes.restype = c_size_t
+    lib.reni_unnormalise_srgb.argtypes = [c_int64, c_int64, c_int64, c_void_p, POINTER(c_int64), c_int32, ctypes.c_double,
+                                          ctypes.c_double, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.reni_unnormalise_srgb.restype = c_int32
+    lib.reni_minmax_normalise.argtypes = [c_int64, c_void_p, ctypes.c_double, ctypes.c_double, c_void_p, c_void_p, c_size_t,
+                                          c_void_p]
+    lib.reni_minmax_normalise.restype = c_int32
     _lib = lib
     return lib
 

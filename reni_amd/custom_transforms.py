@@ -1,9 +1,14 @@
 """HDR normalisation transforms with the reference's names (src/utils/custom_transforms.py:4-33).
 
-Not on the per-sample hot path: they run once per image when a dataset is loaded / a prediction is viewed.
+Tensors that live on the GPU (a model output on its way to the viewer / the FIT_INVERSE renderer, RENI_module.py:108) go
+through the HIP epilogue of libreni_hip.so (``reni_unnormalise_srgb`` / ``reni_minmax_normalise``, reni_tu_image.hip).
+Host tensors -- the dataset loader normalises every image once on the CPU, src/data/datasets.py:95-101 -- are mapped by
+the one-line torch expressions below; that is data preparation in front of the path, not the path.
 ``transform_builder`` covers the transforms that do not need torchvision (absent here and on the GPU box);
 asking for one that does raises with the transform's name."""
 import torch
+
+from . import ops
 
 
 class MinMaxNormalise(object):
@@ -14,10 +19,39 @@ class MinMaxNormalise(object):
         self.minmax = minmax
 
     def __call__(self, img):
-        img = torch.clip(img, img[img > 0.0].min(), img[img < torch.inf].max())
-        img = torch.log(img)
-        img = 2 * (img - self.minmax[0]) / (self.minmax[1] - self.minmax[0]) - 1
-        return img
+        if img.is_cuda:
+            return ops.minmax_normalise(img, self.minmax).to(img.dtype)
+        lo, hi = self.minmax
+        positive, finite = img[img > 0.0], img[img < torch.inf]
+        return 2 * (torch.clip(img, positive.min(), finite.max()).log() - lo) / (hi - lo) - 1
+
+
+def _unnormalise_device(img, minmax):
+    """y = exp(0.5 (x + 1)(m1 - m0) + m0) of a device tensor through reni_unnormalise_srgb, in the tensor's own layout."""
+    if img.dim() in (3, 4) and img.shape[-3] == 3:   # an image batch [B,3,H,W] / [3,H,W], any strides
+        return ops.unnormalise_srgb(img, minmax, srgb=False).view(img.shape).to(img.dtype)
+    if img.dim() == 3 and img.shape[-1] == 3:        # a model output [B,P,3] (RENI_module.py:108), read in place
+        B, P, _ = img.shape
+        lin = ops.unnormalise_srgb(img.view(B, 1, P, 3).permute(0, 3, 1, 2), minmax, srgb=False)  # [B,3,1,P]
+        return lin.permute(0, 2, 3, 1).reshape(B, P, 3).to(img.dtype)
+    flat = img.reshape(1, 1, -1, 1).expand(1, 3, -1, 1)  # any other shape: elementwise, channel axis broadcast
+    return ops.unnormalise_srgb(flat, minmax, srgb=False)[0, 0].reshape(img.shape).to(img.dtype)
+
+
+class _UnnormaliseFn(torch.autograd.Function):
+    """FIT_INVERSE differentiates through the un-normalisation (RENI_module.py:108-112): dy/dx = y (m1 - m0) / 2."""
+
+    @staticmethod
+    def forward(ctx, img, m0, m1):
+        y = _unnormalise_device(img.detach(), (m0, m1))
+        ctx.save_for_backward(y)
+        ctx.k = 0.5 * (m1 - m0)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return gy * y * ctx.k, None, None
 
 
 class UnMinMaxNormlise(object):
@@ -27,9 +61,10 @@ class UnMinMaxNormlise(object):
         self.minmax = minmax
 
     def __call__(self, img):
-        img = 0.5 * (img + 1) * (self.minmax[1] - self.minmax[0]) + self.minmax[0]
-        img = torch.exp(img)
-        return img
+        lo, hi = float(self.minmax[0]), float(self.minmax[1])
+        if img.is_cuda:
+            return _UnnormaliseFn.apply(img, lo, hi) if img.requires_grad else _unnormalise_device(img, (lo, hi))
+        return torch.exp(0.5 * (img + 1) * (hi - lo) + lo)
 
 
 class UnNormalise(object):

@@ -39,8 +39,53 @@ def world_size():
 
 
 def owned_indices(n_items, rank, world):
-    """Indices of the images a rank owns (round-robin, as DistributedSampler(shuffle=False))."""
+    """Indices of the images a rank owns (round-robin, as DistributedSampler(shuffle=False)).  No padding:
+    DistributedSampler pads the short ranks with wrapped-around duplicates so that every rank draws the same count;
+    a duplicate would put one latent row on two owners, so here the COUNT of steps is equalised instead
+    (``epoch_batches``) and a rank that has run out of images joins the step's collective with a zero gradient."""
     return list(range(rank, n_items, world))
+
+
+def steps_per_epoch(n_items, batch_size, world):
+    """Optimiser steps every rank runs per epoch: the longest rank's, ceil(ceil(n / world) / batch_size)."""
+    longest = (n_items + world - 1) // world
+    return (longest + batch_size - 1) // batch_size
+
+
+def epoch_batches(n_items, batch_size, rank, world):
+    """This rank's index lists for one epoch -- exactly ``steps_per_epoch`` of them on EVERY rank (the trailing ones may
+    be short or empty), so the per-step gradient all-reduce and the epoch-end metric all-reduce always pair up."""
+    own = owned_indices(n_items, rank, world)
+    return [own[s * batch_size:(s + 1) * batch_size] for s in range(steps_per_epoch(n_items, batch_size, world))]
+
+
+def merge_owned_rows_(table: torch.Tensor, rank=None, world=None):
+    """After training, every rank holds trained values only in the rows it owns (``i % world == rank``); the others are
+    still at their initial values there.  Sum of the owner-masked tables = the full trained table on every rank: what
+    the reference's DDP keeps at all times by all-reducing the whole latent table.  In place."""
+    w = world_size() if world is None else world
+    if w == 1:
+        return table
+    r = dist.get_rank() if rank is None else rank
+    mask = torch.zeros(table.shape[0], dtype=table.dtype, device=table.device)
+    mask[r::w] = 1
+    merged = table * mask.view(-1, *([1] * (table.dim() - 1)))
+    dist.all_reduce(merged, op=dist.ReduceOp.SUM)
+    table.copy_(merged)
+    return table
+
+
+def gather_shards(shard: torch.Tensor, n_items: int, rank=None, world=None):
+    """Full ``[n_items, ...]`` table from per-rank shards holding rows ``rank, rank + world, ...`` (TrainEngine /
+    bench.py keep only the owned rows resident)."""
+    w = world_size() if world is None else world
+    if w == 1:
+        return shard.clone()
+    r = dist.get_rank() if rank is None else rank
+    full = torch.zeros((n_items,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+    full[r::w] = shard
+    dist.all_reduce(full, op=dist.ReduceOp.SUM)
+    return full
 
 
 def allreduce_mean_(flat: torch.Tensor):

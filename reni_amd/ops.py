@@ -99,11 +99,20 @@ class Plan:
             D = D[:1]
         return B, P, _f32c(D), dbs
 
+    def _check_zp(self, Z, params, map_params=None):
+        """The C ABI takes bare pointers: a mis-shaped latent or parameter buffer would be read out of bounds."""
+        if Z.dim() != 3 or tuple(Z.shape[1:]) != (self.ndims, 3):
+            raise ValueError(f"Z must be [B,{self.ndims},3], got {tuple(Z.shape)}")
+        if params.numel() != self.n_params:
+            raise ValueError(f"params must hold {self.n_params} floats, got {params.numel()}")
+        if map_params is not None and map_params.numel() != self.n_map_params:
+            raise ValueError(f"map_params must hold {self.n_map_params} floats, got {map_params.numel()}")
+
     def forward(self, Z: torch.Tensor, D: torch.Tensor, params: torch.Tensor) -> torch.Tensor:
         _require_cuda(Z, D, params)
         Z = _f32c(Z); params = _f32c(params)
+        self._check_zp(Z, params)
         B, P, Dc, dbs = self._grid_args(Z, D)
-        assert params.numel() == self.n_params and Z.shape[1:] == (self.ndims, 3)
         out = torch.empty(B, P, 3, dtype=torch.float32, device=Z.device)
         ws = self.workspace(B, P, 0, Z.device)
         wp, wn = self._aligned_ptr(ws)
@@ -118,6 +127,7 @@ class Plan:
         (loss_terms[4] device tensor, dZ or None, dparams or None, out or None)."""
         _require_cuda(Z, D, params, target, weight)
         Z = _f32c(Z); params = _f32c(params)
+        self._check_zp(Z, params)
         B, P, Dc, dbs = self._grid_args(Z, D)
         if target.dtype != torch.float32:
             target = target.float()
@@ -148,7 +158,10 @@ class Plan:
     def backward(self, Z, D, params, dout, need_dw=True, need_dz=True):
         _require_cuda(Z, D, params, dout)
         Z = _f32c(Z); params = _f32c(params); dout = _f32c(dout)
+        self._check_zp(Z, params)
         B, P, Dc, dbs = self._grid_args(Z, D)
+        if tuple(dout.shape) != (B, P, 3):
+            raise ValueError(f"dout must be [{B},{P},3], got {tuple(dout.shape)}")
         flags = (_lib.NEED_DW if need_dw else 0) | (_lib.NEED_DZ if need_dz else 0)
         dev = Z.device
         dZ = torch.empty_like(Z) if need_dz else None
@@ -246,8 +259,8 @@ class Plan:
     def film_model_forward(self, Z, D, params, map_params):
         _require_cuda(Z, D, params, map_params)
         Z = _f32c(Z); params = _f32c(params); map_params = _f32c(map_params)
+        self._check_zp(Z, params, map_params)
         B, P, Dc, dbs = self._grid_args(Z, D)
-        assert params.numel() == self.n_params and map_params.numel() == self.n_map_params
         out = torch.empty(B, P, 3, dtype=torch.float32, device=Z.device)
         ws = self.workspace(B, P, 0, Z.device)
         wp, wn = self._aligned_ptr(ws)
@@ -261,6 +274,7 @@ class Plan:
         """-> (loss_terms[4], dZ, dparams or None, dmap_params or None, out or None)"""
         _require_cuda(Z, D, params, map_params, target, weight)
         Z = _f32c(Z); params = _f32c(params); map_params = _f32c(map_params)
+        self._check_zp(Z, params, map_params)
         B, P, Dc, dbs = self._grid_args(Z, D)
         if target.dtype != torch.float32:
             target = target.float()
@@ -291,7 +305,10 @@ class Plan:
     def film_model_backward(self, Z, D, params, map_params, dout, need_dw=True):
         _require_cuda(Z, D, params, map_params, dout)
         Z = _f32c(Z); params = _f32c(params); map_params = _f32c(map_params); dout = _f32c(dout)
+        self._check_zp(Z, params, map_params)
         B, P, Dc, dbs = self._grid_args(Z, D)
+        if tuple(dout.shape) != (B, P, 3):
+            raise ValueError(f"dout must be [{B},{P},3], got {tuple(dout.shape)}")
         flags = (_lib.NEED_DW if need_dw else 0) | _lib.NEED_DZ
         dev = Z.device
         dZ = torch.empty_like(Z)
@@ -345,11 +362,15 @@ def profile_enable(on: bool = True):
     _lib.check(_lib.load().reni_profile_enable(1 if on else 0))
 
 
-def profile_read(reset: bool = True):
-    """-> (summed kernel milliseconds, number of launches) since the last reset."""
+PROF_FWD_BWD, PROF_STATS, PROF_FWD, PROF_ALL = 0, 1, 2, -1
+
+
+def profile_read(reset: bool = True, kind: int = PROF_FWD_BWD):
+    """-> (summed kernel milliseconds, number of launches) of one kind of launch since the last reset
+    (kind: the fused forward+loss+backward pass, RENITestLoss's statistics pass, plain inference, or all)."""
     tot = ctypes.c_double(0.0)
     n = ctypes.c_int64(0)
-    _lib.check(_lib.load().reni_profile_read(ctypes.byref(tot), ctypes.byref(n), 1 if reset else 0))
+    _lib.check(_lib.load().reni_profile_read_kind(int(kind), ctypes.byref(tot), ctypes.byref(n), 1 if reset else 0))
     return tot.value, n.value
 
 
@@ -395,3 +416,52 @@ def envmap_shade(normals, positions, camera_center, light_dirs, light_colors, sh
 def envmap_shade_backward(normals, positions, camera_center, light_dirs, dcolors, shininess, kd, ks):
     """d loss / d light_colors [B,J,3] for an upstream d loss / d colors [B,NP,3]."""
     return _shade_call(False, normals, positions, camera_center, light_dirs, dcolors, shininess, kd, ks)
+
+
+def _ws256(nbytes, device):
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+    p = ws.data_ptr()
+    ap = (p + 255) & ~255
+    return ws, ap, ws.numel() - (ap - p)
+
+
+def unnormalise_srgb(img: torch.Tensor, minmax=None, srgb: bool = True, want_linear: bool = False):
+    """reni_unnormalise_srgb: UnMinMaxNormlise(minmax) (skipped when minmax is None) -> sRGB view, on the device.
+    img: [B,3,H,W] or [3,H,W], ANY strides (e.g. a model output viewed as ``out.view(B,H,W,3).permute(0,3,1,2)`` is read
+    in place).  Returns the sRGB batch [B,3,H,W] (srgb=True), the linear HDR batch (srgb=False), or both (want_linear)."""
+    _require_cuda(img)
+    lib = _lib.load()
+    if img.dim() == 3:
+        img = img.unsqueeze(0)
+    if img.dim() != 4 or img.shape[1] != 3:
+        raise ValueError(f"expected [B,3,H,W] or [3,H,W], got {tuple(img.shape)}")
+    if img.dtype != torch.float32:
+        img = img.float()
+    B, _, H, W = img.shape
+    st = (ctypes.c_int64 * 4)(*img.stride())
+    dev = img.device
+    out = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev) if srgb else None
+    lin = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev) if (want_linear or not srgb) else None
+    ws, wp, wn = _ws256(int(lib.reni_image_workspace_bytes(B, H, W)), dev) if srgb else (None, None, 0)
+    m0, m1 = (float(minmax[0]), float(minmax[1])) if minmax is not None else (0.0, 1.0)
+    with torch.cuda.device(dev):
+        _lib.check(lib.reni_unnormalise_srgb(B, H, W, img.data_ptr(), st, 0 if minmax is None else 1, m0, m1, 1 if srgb else 0,
+                                             out.data_ptr() if out is not None else None,
+                                             lin.data_ptr() if lin is not None else None, wp, wn,
+                                             torch.cuda.current_stream(dev).cuda_stream))
+    if srgb and want_linear:
+        return out, lin
+    return out if srgb else lin
+
+
+def minmax_normalise(img: torch.Tensor, minmax):
+    """reni_minmax_normalise: MinMaxNormalise(minmax) of ONE image (any shape; the clip bounds are the image's own)."""
+    _require_cuda(img)
+    lib = _lib.load()
+    x = _f32c(img)
+    out = torch.empty_like(x)
+    ws, wp, wn = _ws256(256, x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.reni_minmax_normalise(x.numel(), x.data_ptr(), float(minmax[0]), float(minmax[1]), out.data_ptr(), wp, wn,
+                                             torch.cuda.current_stream(x.device).cuda_stream))
+    return out

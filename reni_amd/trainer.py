@@ -11,8 +11,17 @@ import torch
 from . import dist as rdist
 
 
+LATENT_NAMES = ("Z", "mu", "log_var")
+
+
 def _decoder_params(model):
-    return [p for p in model.net.parameters() if p.requires_grad]
+    """Every trainable parameter that is NOT a latent table: the SIREN, and for the FiLM variants also ``final_layer``
+    and ``mapping_network`` (reference: DDP all-reduces every trainable parameter, run.py:97)."""
+    return [p for n, p in model.named_parameters() if n not in LATENT_NAMES and p.requires_grad]
+
+
+def _latent_params(model):
+    return [(n, getattr(model, n)) for n in LATENT_NAMES if isinstance(getattr(model, n, None), torch.nn.Parameter)]
 
 
 def sync_decoder_grads(model):
@@ -21,7 +30,10 @@ def sync_decoder_grads(model):
     w = rdist.world_size()
     if w == 1:
         return
-    ps = [p for p in _decoder_params(model) if p.grad is not None]
+    ps = _decoder_params(model)
+    for p in ps:  # a rank whose batch was empty (fewer owned images) still joins the collective, with zeros
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
     if ps:
         flat = torch.cat([p.grad.reshape(-1) for p in ps])
         rdist.allreduce_mean_(flat)
@@ -30,10 +42,25 @@ def sync_decoder_grads(model):
             n = p.numel()
             p.grad.copy_(flat[o:o + n].view_as(p.grad))
             o += n
-    for name in ("Z", "mu", "log_var"):
-        p = getattr(model, name, None)
-        if p is not None and p.grad is not None:
+    for _, p in _latent_params(model):
+        if p.grad is not None:
             p.grad.mul_(1.0 / w)
+
+
+def gather_latents(model, optimizer=None):
+    """Merge the owner-trained latent rows (and, given the optimiser, their Adam moments) into the full table on every
+    rank.  Called at the end of ``fit`` and before any checkpoint, so that ``state_dict()`` taken on rank 0 equals the
+    one-process run's (the reference's DDP keeps the full table identical on every rank)."""
+    if rdist.world_size() == 1:
+        return
+    with torch.no_grad():
+        for _, p in _latent_params(model):
+            rdist.merge_owned_rows_(p.data)
+            st = optimizer.state.get(p) if optimizer is not None else None
+            if st:
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if k in st:
+                        rdist.merge_owned_rows_(st[k])
 
 
 def fit(module, max_epochs=None, device=None, batches=None, rank=0, world=1):
@@ -46,7 +73,8 @@ def fit(module, max_epochs=None, device=None, batches=None, rank=0, world=1):
     module.on_fit_start()
     module.to(device)
     if world > 1:
-        for p in module.model.net.parameters():
+        assert len(module.dataset) >= world, "fewer images than ranks: a rank would have nothing to report at epoch end"
+        for p in _decoder_params(module.model):
             rdist.broadcast_(p.data, 0)
     cfg = module.configure_optimizers()
     opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
@@ -61,23 +89,28 @@ def fit(module, max_epochs=None, device=None, batches=None, rank=0, world=1):
                 imgs = torch.stack([module.dataset[i][0] for i in idx])
                 it.append((imgs, torch.tensor(idx)))
         else:
-            own = rdist.owned_indices(len(module.dataset), rank, world)
-            bs = module.batch_size
+            # the same number of steps on every rank (a short rank's trailing batches are short or empty)
             it = []
-            for s in range(0, len(own), bs):
-                idx = own[s:s + bs]
-                it.append((torch.stack([module.dataset[i][0] for i in idx]), torch.tensor(idx)))
+            for idx in rdist.epoch_batches(len(module.dataset), module.batch_size, rank, world):
+                imgs = torch.stack([module.dataset[i][0] for i in idx]) if idx else None
+                it.append((imgs, torch.tensor(idx, dtype=torch.long)))
         for bi, (imgs, idx) in enumerate(it):
-            out = module.training_step((imgs.to(device), idx.to(device)), bi)
             opt.zero_grad(set_to_none=True)
-            out["loss"].backward()
+            if imgs is not None:
+                out = module.training_step((imgs.to(device), idx.to(device)), bi)
+                out["loss"].backward()
+                outs.append({k: v.detach() for k, v in out.items()})
+            else:  # no image left on this rank: the dense latent Adam still takes its (zero-gradient, momentum-only) step
+                for _, p in _latent_params(module.model):
+                    if p.requires_grad:
+                        p.grad = torch.zeros_like(p)
             sync_decoder_grads(module.model)
             opt.step()
             module.global_step += 1
-            outs.append({k: v.detach() for k, v in out.items()})
         module.training_epoch_end(outs)
-        history.append({k: float(torch.stack([o[k] for o in outs]).mean()) for k in outs[0]})
+        history.append({k: float(torch.stack([o[k] for o in outs]).mean()) for k in outs[0]} if outs else {})
         if sched is not None:
             sched.step()
         module.maybe_double_resolution()
+    gather_latents(module.model, opt)
     return history

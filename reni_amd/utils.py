@@ -54,9 +54,12 @@ def get_mask(sidelen, path):
 
 
 def sRGB(imgs):
-    """Linear HDR -> sRGB for viewing (utils.py:30-42)."""
+    """Linear HDR -> sRGB for viewing (utils.py:30-42).  Device tensors: the HIP epilogue (reni_unnormalise_srgb)."""
     if len(imgs.shape) == 3:
         imgs = imgs.unsqueeze(0)
+    if imgs.is_cuda:
+        from . import ops
+        return ops.unnormalise_srgb(imgs, None, srgb=True).to(imgs.dtype)
     q = torch.quantile(torch.quantile(torch.quantile(imgs, 0.98, dim=(1)), 0.98, dim=(1)), 0.98, dim=(1))
     imgs = torch.clamp(imgs / q.unsqueeze(1).unsqueeze(2).unsqueeze(3), 0.0, 1.0)
     return torch.where(imgs <= 0.0031308, 12.92 * imgs, 1.055 * torch.pow(torch.abs(imgs), 1 / 2.4) - 0.055)

@@ -87,3 +87,18 @@ def test_mfma_results_are_never_read_before_their_write_back():
     assert sum("k_reni_main" in f for f in kernels) >= 40  # 2 precisions x 4 widths x 3 modes x {concat, FiLM}, minus MFMA-free ones
     assert not bad, "MFMA result accessed too early: " + "; ".join(
         f"{f[:48]} {k} {st} states (asm lines {a}->{b})" for f, k, st, a, b in bad[:8])
+
+
+def test_release_library_has_no_result_changing_debug_knobs():
+    """The ablation mask (RENI_DEBUG_MASK: skips weight-gradient phases / LDS staging, i.e. WRONG results by design) and
+    the cycle-trace pointer exist only in -DRENI_DEBUG / -DRENI_TRACE builds: the shipped library must not even contain
+    the environment variables' names, so a stray variable cannot change what it computes."""
+    so = os.path.join(ROOT, "reni_amd", "lib", "libreni_hip.so")
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+        g.build()
+    blob = open(so, "rb").read()
+    for name in (b"RENI_DEBUG_MASK", b"RENI_TRACE_PTR"):
+        assert name not in blob, name
+    # the two path selectors that remain pick between paths that are both correct (and both tested)
+    assert b"RENI_NO_PERSIST" in blob and b"RENI_NO_SIDE_STREAM" in blob

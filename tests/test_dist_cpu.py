@@ -25,6 +25,17 @@ class _FakeModel(torch.nn.Module):
         self.Z = torch.nn.Parameter(torch.zeros(6, 2, 3))
 
 
+class _FakeFilmModel(torch.nn.Module):
+    """The FiLM variants' trainable parts outside ``net`` (reni_amd/film.py): final_layer, mapping_network."""
+    def __init__(self):
+        super().__init__()
+        self.net = torch.nn.Sequential(torch.nn.Linear(4, 3))
+        self.final_layer = torch.nn.Linear(3, 3)
+        self.mapping_network = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 6))
+        self.mu = torch.nn.Parameter(torch.zeros(5, 2, 3))
+        self.log_var = torch.nn.Parameter(torch.zeros(5, 2, 3))
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -57,6 +68,40 @@ def _worker(rank, world, port, q):
     ok = ok and own == list(range(rank, 6, 2))
     v = rdist.allreduce_mean_scalars(torch.tensor([float(rank)]))
     ok = ok and abs(float(v) - 0.5) < 1e-6
+    # FiLM: every trainable non-latent parameter is synchronised, also with a missing gradient (empty batch on a rank)
+    torch.manual_seed(1)
+    f = _FakeFilmModel()
+    names = [n for n, _ in f.named_parameters() if n not in trainer.LATENT_NAMES]
+    ok = ok and len(trainer._decoder_params(f)) == len(names) == 8
+    for i, (n, p) in enumerate(f.named_parameters()):
+        if n in trainer.LATENT_NAMES:
+            continue
+        p.grad = None if rank == 1 else torch.full_like(p, 2.0 + i)
+    f.mu.grad = torch.full_like(f.mu, 6.0)
+    trainer.sync_decoder_grads(f)
+    for i, (n, p) in enumerate(f.named_parameters()):
+        if n not in trainer.LATENT_NAMES:
+            ok = ok and torch.allclose(p.grad, torch.full_like(p, (2.0 + i) / 2))
+    ok = ok and torch.allclose(f.mu.grad, torch.full_like(f.mu, 3.0)) and f.log_var.grad is None
+    # uneven ownership (5 images, 2 ranks, batch 2): both ranks run the same number of steps
+    nb = rdist.epoch_batches(5, 2, rank, world)
+    ok = ok and len(nb) == rdist.steps_per_epoch(5, 2, world) == 2
+    ok = ok and nb == ([[0, 2], [4]] if rank == 0 else [[1, 3], []])
+    ok = ok and rdist.steps_per_epoch(201, 100, 2) == 2 and rdist.steps_per_epoch(615, 100, 8) == 1
+    # latent merge: rows trained by their owner end up on every rank, moments included
+    with torch.no_grad():
+        f.mu.zero_()
+        f.mu[rank::world] = 10.0 + rank
+        f.mu[(1 - rank)::world] = -1.0  # stale values of rows this rank does not own
+    opt = torch.optim.Adam([f.mu], lr=1e-3)
+    opt.state[f.mu] = {"step": torch.tensor(1.0), "exp_avg": f.mu.detach().clone() * 2, "exp_avg_sq": f.mu.detach().clone() * 3}
+    trainer.gather_latents(f, opt)
+    want = torch.tensor([10.0, 11.0, 10.0, 11.0, 10.0]).view(5, 1, 1).expand(5, 2, 3)
+    ok = ok and torch.equal(f.mu.detach(), want) and torch.equal(opt.state[f.mu]["exp_avg"], want * 2)
+    ok = ok and torch.equal(opt.state[f.mu]["exp_avg_sq"], want * 3)
+    shard = torch.full((len(rdist.owned_indices(5, rank, world)), 2), float(rank))
+    full = rdist.gather_shards(shard, 5)
+    ok = ok and torch.equal(full[:, 0], torch.tensor([0.0, 1.0, 0.0, 1.0, 0.0]))
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

@@ -107,3 +107,37 @@ def test_two_rank_step_equals_one_rank_step_on_the_union_batch():
     assert float(d.max()) <= 1.1 * LR * STEPS
     for _, _, Zr, rws in res:
         assert float((Zr - lat[torch.tensor(rws, device=dev)].cpu()).abs().max()) <= 2e-5
+
+
+def _run_bench(extra_env, *args):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 alone prints, and exactly one line
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's N > 1 form is torchrun, but the command must
+    also stand alone): two rank processes are started before anything touches the GPU.  Here both share cuda:0 over
+    gloo; with two GPUs the same path runs on RCCL (next test)."""
+    line = _run_bench({"RENI_SHARE_GPU": "1", "RENI_DIST_BACKEND": "gloo"}, "--gpus", "2", "--steps", "2", "--warmup", "1",
+                      "--batch", "8", "--no-cpu-baseline")
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["dist_backend"] == "gloo"
+    assert line["config"]["global_batch_images"] == 16 and line["value"] > 0
+    assert line["roofline"]["kernel_launches"] == 2
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")
+def test_bench_two_ranks_over_rccl():
+    """The exchange step on the real transport: backend "nccl" (= RCCL) on two GPUs, self-launched."""
+    line = _run_bench({}, "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["dist_backend"] == "nccl"
+    one = _run_bench({}, "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert line["value"] > 1.2 * one["value"]  # weak scaling: two ranks do twice the work per step

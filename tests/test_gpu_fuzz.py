@@ -46,10 +46,12 @@ def test_fuzz_against_oracle(c):
     if c["dtype"] == "bf16" and L > 5:
         tol["grad"] *= (L + 2) / 6.0  # deeper than any shipped configuration: bf16 rounding compounds per layer (600-case run)
     if c["dtype"] == "bf16" and B * P < 8:
-        # a gradient from fewer than eight samples through up to eight sine layers is ill-conditioned: on the one-sample
-        # case of a 600-case run fp32 itself kept 3.5 digits (3e-4) and bf16 none (tests/gpu_fuzz_one.py); outputs and loss
-        # are still checked
-        tol["grad"] = 1.0
+        # A gradient from fewer than eight samples through up to eight sine layers is ill-conditioned: on the one-sample
+        # case of a 600-case run fp32 itself kept 3.5 digits (3e-4) and bf16 none (tests/gpu_fuzz_one.py).  A bf16 gradient
+        # comparison would assert nothing there, so these shapes (launch geometry, ragged single tile, masking) are
+        # checked through the fp32 kernels instead, at the precision fp32 keeps on them.
+        c = dict(c, dtype="f32")
+        tol = dict(loss=5e-6, grad=1e-3)
     elif c["dtype"] == "bf16" and B * P < 256:
         tol["grad"] = 8e-2  # a handful of samples: no averaging over directions behind the bf16 rounding of each (a 7-layer
         # FiLM net with one image of 129 directions reached 4.3e-2 on its mapping network's first layer in a 240-case run)

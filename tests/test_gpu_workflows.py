@@ -264,3 +264,75 @@ def test_adam_rows_step_is_dense_adam_over_the_table(dev):
         opt.step()
         ops.adam_rows_step(t, gr.to(dev), idx.to(dev), m, v, step, 1e-2, grad_scale=0.5)
     assert float((t.cpu() - ref.detach()).abs().max()) <= 2e-6
+
+
+def test_c4_full_size_latent_step_bf16(dev):
+    """BASELINE config 4 at its real size (examples.ipynb cell 4; RENI_module.py:92-94,126-128): 21 held-out maps x 32 768
+    directions, ND = 36, 5 x 128, bf16, frozen decoder, masked weight, RENITestLoss(1e-7, 1e-4) -- the statistics
+    instance, the cosine coefficients and the frozen instance of the persistent kernel with a mask, which the G7
+    miniature (3 x 2 048, fp32, H = 64) never reaches.  One image is checked against the oracle at full P; the batch
+    through additivity over images and run-to-run bit-equality."""
+    spec = O.DecoderSpec(36, "SO2", 128, 5, 3, True, "tanh")
+    B = 21
+    params, Z, D, W, T = random_problem(spec, B, 0, seed=44, grid_w=256)
+    P = D.shape[1]
+    assert P == 32768
+    keep = (torch.arange(256) < int(0.188 * 256)).float().view(1, 1, 256, 1).expand(1, 128, 256, 3).reshape(1, P, 3)
+    Wm = W * keep                                            # Mask-3's kept fraction (SURVEY App. D)
+    plan = make_plan(spec, "bf16")
+    fp = flat_params(spec, params).to(dev)
+    Zd, Dd, Td, Wd = Z.to(dev), D.to(dev), T.to(dev), Wm.to(dev)
+    a, b_ = 1e-7, 1e-4
+
+    def run(sel):
+        lt, dZ, dp, _ = plan.forward_loss_backward(Zd[sel], Dd, fp, Td[sel], Wd, loss_kind="test", alpha=a, beta=b_,
+                                                   need_dw=False)
+        assert dp is None
+        return lt.cpu().double(), dZ.cpu()
+
+    lt_all, dZ_all = run(slice(0, B))
+    lt_again, dZ_again = run(slice(0, B))
+    assert torch.equal(lt_all, lt_again) and torch.equal(dZ_all, dZ_again)          # deterministic reductions
+    # one image against the oracle at full P (reference-shaped: 32 768 x 1 370 encoding, autograd)
+    k = 7
+    ref = O.fwd_loss_bwd(spec, params, Z[k:k + 1], D, T[k:k + 1], Wm, "test", a, b_, need_dw=False)
+    lt_k, dZ_k = run(slice(k, k + 1))
+    for i in range(4):
+        assert abs(float(lt_k[i]) - ref["loss_terms"][i]) <= 3e-3 * abs(ref["loss_terms"][0]), (i, lt_k, ref["loss_terms"])
+    assert abs(float(lt_k[3]) - ref["loss_terms"][3]) <= 3e-3 * abs(ref["loss_terms"][3])  # the cosine term on its own scale
+    assert O.rel_l2(dZ_k.numpy(), ref["dZ"].numpy()) <= 3e-2
+    assert torch.equal(dZ_k[0], dZ_all[k])       # an image's latent gradient does not depend on its batch
+    # additivity: every loss term of the batch is the sum over its images (in groups, to keep the test short)
+    groups = [slice(0, 5), slice(5, 6), slice(6, 13), slice(13, 21)]
+    parts = [run(g) for g in groups]
+    lt_sum = sum(p[0] for p in parts)
+    for i in range(4):
+        assert abs(float(lt_sum[i] - lt_all[i])) <= 2e-6 * abs(float(lt_all[i])) + 1e-12, (i, lt_sum, lt_all)
+    assert torch.equal(torch.cat([p[1] for p in parts]), dZ_all)
+    assert float(dZ_all.abs().max()) > 0 and torch.isfinite(dZ_all).all()
+
+
+def test_reni_forward_is_the_models_forward(dev):
+    """RENI.forward(z) (RENI_module.py:75-78): the module's own inference entry -- the model on the module's grid, for the
+    two tensor forms the reference's body (z.size(0)) admits: a latent tensor and a 1-D index tensor."""
+    from reni_amd.lightning_module import RENI
+    g = load_golden("g6_train_steps.npz")
+    ds = _ListDataset(torch.from_numpy(g["imgs"]))
+    mod = RENI(_config(), "FIT_DECODER", dataset=ds)
+    mod.setup()
+    mod.model.load_state_dict({"model." + k: v for k, v in sd_from(g, "sd0.").items()})
+    mod.to(dev)
+    spec = O.DecoderSpec(9, "SO2", 64, 3, 3, True, "tanh")
+    params = {k: v for k, v in sd_from(g, "sd0.").items() if k != "Z"}
+    Z0 = sd_from(g, "sd0.")["Z"]
+    D = O.get_directions(32)
+    with torch.no_grad():
+        z = mod.model.Z[:2].detach()
+        out_latent = mod(z)
+        out_idx = mod(torch.tensor([0, 1], device=dev))
+        out_one = mod(torch.tensor([1], device=dev))
+    ref = O.reni_forward(spec, params, Z0[:2], D.expand(2, -1, 3))
+    assert out_latent.shape == (2, 512, 3)
+    assert float((out_latent.cpu() - ref).abs().max()) <= 1e-5
+    assert torch.equal(out_idx, out_latent)
+    assert torch.equal(out_one, out_latent[1:2])

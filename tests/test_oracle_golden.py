@@ -84,6 +84,14 @@ def test_g4_small_fwd_bwd(golden, name, eq, lll, act):
     assert O.rel_l2(f["dZ"], g["dZ"]) < 2e-5
     for k in params:
         assert O.rel_l2(f["grads"][k], g["g." + k]) < 2e-5, k
+    # fp32 torch restatement of the factored algebra (bench.py's "factored" CPU figure) vs the reference's goldens
+    if act != "exp":
+        ft = O.factored_torch_fwd_loss_bwd(spec, params, Z, D, t, S.repeat(2, 1, 1))
+        np.testing.assert_allclose(ft["out"].numpy(), g["out"], atol=5e-6)
+        assert abs(ft["loss_terms"][0] - float(g["loss"])) < 2e-6 * abs(float(g["loss"]))
+        assert O.rel_l2(ft["dZ"].numpy(), g["dZ"]) < 2e-5
+        for k in params:
+            assert O.rel_l2(ft["grads"][k].numpy(), g["g." + k]) < 2e-5, k
 
 
 def test_g4_c2_shape(golden):
