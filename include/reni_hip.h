@@ -128,6 +128,16 @@ int reni_forward_loss_backward(const reni_plan* plan, int64_t B, int64_t P, cons
                                float* loss_terms, float* dZ, float* dparams, void* ws,
                                size_t ws_bytes, void* stream);
 
+/* The same with the batch's latents given as ROWS OF A TABLE: image b uses Z_table[idx[b]] ([n_rows][ndims][3], idx on the
+ * device) -- `Z = self.model.Z[idx, :, :]` of the training step (RENI_module.py:97-103) happens inside the prologue kernel
+ * instead of as a separate gather.  dZ is [B][ndims][3] in batch order, as above. */
+int reni_forward_loss_backward_rows(const reni_plan* plan, int64_t B, int64_t P, const float* Z_table, const int64_t* idx,
+                                    const float* D, int64_t d_batch_stride, const float* params, const float* target,
+                                    const int64_t target_strides[3], const float* weight, const int64_t weight_strides[3],
+                                    int32_t loss_kind, float alpha, float beta, uint32_t flags, float* out,
+                                    float* loss_terms, float* dZ, float* dparams, void* workspace, size_t workspace_bytes,
+                                    void* stream);
+
 /* Backward for an arbitrary upstream gradient dout[B,P,3] (generic autograd use of
  * model(Z,D)); the forward is recomputed inside the same fused kernel. */
 int reni_backward(const reni_plan* plan, int64_t B, int64_t P, const float* Z, const float* D,
@@ -197,6 +207,13 @@ int reni_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 int reni_adam_rows_step(float* p, const float* g_rows, const int64_t* idx, int64_t B, int64_t row_len, float* m, float* v,
                         int64_t n_rows, float lr, float b1, float b2, float eps, int64_t step, float grad_scale,
                         void* stream);
+
+/* One launch for both updates of a training step: reni_adam_step on the flat decoder buffer (p, g, m, v, n) and
+ * reni_adam_rows_step on the latent table (table, g_rows, idx, B, row_len, tm, tv, n_rows) with the same
+ * hyper-parameters -- the reference has ONE torch.optim.Adam over the decoder and the latent table (RENI_module.py:178-192). */
+int reni_adam_step2(float* p, const float* g, float* m, float* v, int64_t n, float* table, const float* g_rows,
+                    const int64_t* idx, int64_t B, int64_t row_len, float* tm, float* tv, int64_t n_rows, float lr, float b1,
+                    float b2, float eps, int64_t step, float grad_scale, void* stream);
 
 /* Self-test of the MFMA fragment layouts the kernels rely on; out (host pointer) receives the
  * number of mismatching elements per probe (0 = layout as assumed). */

@@ -58,6 +58,13 @@ struct MainArgs {
   float* dfr;
   int* run_image;
   int kmax;
+  // persistent TRAINING kernel (k_reni_train_bf16<H, true>): a workgroup owns a CONTIGUOUS range of tiles and keeps the
+  // per-image sums (layer-0 dA [H][8], loss) on chip; they leave the chip once per image run: run k of workgroup w is
+  // pruns[(w * pkmax + k)][H * 8 + 16] (dA, then one loss slot per wave) with prun_image[w * pkmax + k] = image (-1: unused)
+  float* pruns;
+  int* prun_image;
+  int pkmax;
+  int nwg_main;  // grid of the training kernel (k_reni_dw1 walks each workgroup's range backwards: most recent first)
 };
 
 // sets reni_last_error()'s thread-local message and returns `code` (defined next to the C ABI, reni_capi.inc)
@@ -70,6 +77,8 @@ hipError_t launch_film_f32(int H, int mode, const MainArgs& a, int nwg, hipStrea
 hipError_t launch_film_bf16(int H, int mode, const MainArgs& a, int nwg, hipStream_t s);
 
 struct PrepArgs {
+  const long long* idx;  // optional: image b's latent is row idx[b] of Z (a latent TABLE); the batch's rows are copied to Zc
+  float* Zc;             // [B][nd][3] compact copy of the gathered rows (read by the epilogue kernels), with idx only
   const float* Z;
   const float* W0;
   const float* b0;

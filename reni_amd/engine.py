@@ -35,20 +35,23 @@ class TrainEngine:
     def step(self, idx: torch.Tensor, target: torch.Tensor, weight: torch.Tensor, directions: torch.Tensor):
         """idx: rows of this rank's latent table in the batch; target/weight: strided [B,P,3] views.
         Returns the device tensor (loss, mse, prior, cosine) of this rank's batch."""
-        Z = self.latent.data[idx]
+        # (the batch's latent rows are gathered inside the prologue kernel: no separate Z[idx] gather)
         terms, dZ, dparams, _ = self.plan.forward_loss_backward(
-            Z, directions, self.flat, target, weight, loss_kind=self.loss_kind, alpha=self.alpha, beta=self.beta,
-            need_dw=self.train_decoder, need_dz=True)
+            self.latent.data, directions, self.flat, target, weight, loss_kind=self.loss_kind, alpha=self.alpha,
+            beta=self.beta, need_dw=self.train_decoder, need_dz=True, idx=idx)
         self.t += 1
         inv_w = 1.0 / self.world
-        work = None
-        if self.train_decoder and self.world > 1:  # the one collective of the step; the latent update runs beside it
-            work = torch.distributed.all_reduce(dparams, op=torch.distributed.ReduceOp.SUM, async_op=True)
         # dense Adam over the whole (owned) latent table, as the reference does (rows outside the
         # batch have zero gradient but still move by momentum -- SURVEY.md Appendix B9)
+        if self.train_decoder and self.world == 1:  # both updates in one launch
+            ops.adam_step2(self.flat, dparams, self.m_dec, self.v_dec, self.latent.data, dZ, idx, self.m_lat, self.v_lat,
+                           self.t, self.lr, grad_scale=inv_w)
+            return terms
+        work = None
+        if self.train_decoder:  # the one collective of the step; the latent update runs beside it
+            work = torch.distributed.all_reduce(dparams, op=torch.distributed.ReduceOp.SUM, async_op=True)
         ops.adam_rows_step(self.latent.data, dZ, idx, self.m_lat, self.v_lat, self.t, self.lr, grad_scale=inv_w)
         if self.train_decoder:
-            if work is not None:
-                work.wait()
+            work.wait()
             ops.adam_step(self.flat, dparams, self.m_dec, self.v_dec, self.t, self.lr, grad_scale=inv_w)
         return terms

@@ -122,13 +122,21 @@ class Plan:
         return out
 
     def forward_loss_backward(self, Z, D, params, target, weight, loss_kind="mse", alpha=0.0, beta=0.0,
-                              need_dw=True, need_dz=True, want_out=False):
+                              need_dw=True, need_dz=True, want_out=False, idx=None):
         """target / weight: any strided [B,P,3] views (stride 0 broadcasts); returns
-        (loss_terms[4] device tensor, dZ or None, dparams or None, out or None)."""
-        _require_cuda(Z, D, params, target, weight)
+        (loss_terms[4] device tensor, dZ or None, dparams or None, out or None).
+        idx (int64 device tensor [B]): Z is a latent TABLE and image b uses row idx[b] (gathered inside the prologue
+        kernel: reni_forward_loss_backward_rows); dZ stays [B,ND,3] in batch order."""
+        _require_cuda(Z, D, params, target, weight, idx)
         Z = _f32c(Z); params = _f32c(params)
         self._check_zp(Z, params)
-        B, P, Dc, dbs = self._grid_args(Z, D)
+        if idx is not None:
+            if idx.dtype != torch.int64 or idx.dim() != 1 or idx.numel() < 1:
+                raise ValueError("idx must be a non-empty 1-D int64 tensor")
+            idx = idx.contiguous()
+            B, P, Dc, dbs = self._grid_args(Z[:1].expand(idx.numel(), -1, -1), D)  # (the batch's shape; Z stays the table)
+        else:
+            B, P, Dc, dbs = self._grid_args(Z, D)
         if target.dtype != torch.float32:
             target = target.float()
         if weight.dtype != torch.float32:
@@ -140,19 +148,20 @@ class Plan:
         flags = (_lib.NEED_DW if need_dw else 0) | (_lib.NEED_DZ if need_dz else 0)
         dev = Z.device
         loss_terms = torch.empty(4, dtype=torch.float32, device=dev)
-        dZ = torch.empty_like(Z) if need_dz else None
+        dZ = torch.empty(B, self.ndims, 3, dtype=torch.float32, device=dev) if need_dz else None
         dparams = torch.empty(self.n_params, dtype=torch.float32, device=dev) if need_dw else None
         out = torch.empty(B, P, 3, dtype=torch.float32, device=dev) if want_out else None
         ws = self.workspace(B, P, flags, dev)
         wp, wn = self._aligned_ptr(ws)
         stream = torch.cuda.current_stream(dev).cuda_stream
         kind = {"mse": _lib.LOSS_MSE, "test": _lib.LOSS_TEST}[loss_kind]
-        _lib.check(self.lib.reni_forward_loss_backward(
-            self._h, B, P, Z.data_ptr(), Dc.data_ptr(), dbs, params.data_ptr(), target.data_ptr(), ts,
-            weight.data_ptr(), wst, kind, float(alpha), float(beta), flags,
-            out.data_ptr() if out is not None else None, loss_terms.data_ptr(),
-            dZ.data_ptr() if dZ is not None else None, dparams.data_ptr() if dparams is not None else None,
-            wp, wn, stream))
+        tail = (Dc.data_ptr(), dbs, params.data_ptr(), target.data_ptr(), ts, weight.data_ptr(), wst, kind, float(alpha),
+                float(beta), flags, out.data_ptr() if out is not None else None, loss_terms.data_ptr(),
+                dZ.data_ptr() if dZ is not None else None, dparams.data_ptr() if dparams is not None else None, wp, wn, stream)
+        if idx is not None:
+            _lib.check(self.lib.reni_forward_loss_backward_rows(self._h, B, P, Z.data_ptr(), idx.data_ptr(), *tail))
+        else:
+            _lib.check(self.lib.reni_forward_loss_backward(self._h, B, P, Z.data_ptr(), *tail))
         return loss_terms, dZ, dparams, out
 
     def backward(self, Z, D, params, dout, need_dw=True, need_dz=True):
@@ -347,6 +356,25 @@ def adam_rows_step(table: torch.Tensor, g_rows: torch.Tensor, idx: torch.Tensor,
     stream = torch.cuda.current_stream(table.device).cuda_stream
     _lib.check(lib.reni_adam_rows_step(table.data_ptr(), g_rows.data_ptr(), idx.data_ptr(), idx.numel(), row_len, m.data_ptr(),
                                        v.data_ptr(), n_rows, float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
+                                       float(grad_scale), stream))
+
+
+def adam_step2(p, g, m, v, table, g_rows, idx, tm, tv, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+               grad_scale: float = 1.0):
+    """adam_step on the flat decoder buffer and adam_rows_step on the latent table in ONE launch (reni_adam_step2)."""
+    _require_cuda(p, g, m, v, table, g_rows, idx, tm, tv)
+    lib = _lib.load()
+    for t in (p, g, m, v, table, g_rows, tm, tv):
+        assert t.is_contiguous()
+    idx = idx.to(torch.int64).contiguous()
+    n_rows = table.shape[0]
+    row_len = table.numel() // max(n_rows, 1)
+    assert g_rows.numel() == idx.numel() * row_len
+    stream = torch.cuda.current_stream(p.device).cuda_stream
+    with torch.cuda.device(p.device):
+        _lib.check(lib.reni_adam_step2(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), table.data_ptr(),
+                                       g_rows.data_ptr(), idx.data_ptr(), idx.numel(), row_len, tm.data_ptr(), tv.data_ptr(),
+                                       n_rows, float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
                                        float(grad_scale), stream))
 
 

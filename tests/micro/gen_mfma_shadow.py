@@ -89,7 +89,7 @@ def kernel(name, acc, nch, kind, F, lds_a=0):
     outs += [f'[e{r}] "+v"(e[{r}])' for r in range(4)]
     outs += ['[s0] "+s"(s0)']
     ins = ['[a] "v"(a)', '[b] "v"(b)', '[la] "v"(la)']
-    clob = f': {agpr_clob}' if agpr_clob else ''
+    clob = f': "scc", {agpr_clob}' if agpr_clob else ': "scc"'
     zero_code = agpr_zero(nch) if acc == "a" else ""
     body_code = body(acc, nch, kind, F, lds_a)
     sum_code = agpr_sum(nch) if acc == "a" else "for (int q = 0; q < %d; ++q) for (int k = 0; k < 16; ++k) r += c[q][k];" % nch
@@ -143,6 +143,10 @@ def main():
                     if acc == "v" and kind in ("fma", "cvt", "salu"):
                         continue
                     variants.append((acc, nch, kind, F, 0))
+    for acc in ("a", "v"):  # ONE chain with fillers between dependent MFMAs (MI355X_MICROARCH.md:443 warns of a cliff)
+        for kind in ("add", "act"):
+            for F in (1, 2, 3, 5, 8):
+                variants.append((acc, 1, kind, F, 0))
     for acc in ("a", "v"):
         for D in (1, 2, 3):
             for F in (0, 3, 5):

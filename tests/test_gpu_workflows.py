@@ -336,3 +336,34 @@ def test_reni_forward_is_the_models_forward(dev):
     assert float((out_latent.cpu() - ref).abs().max()) <= 1e-5
     assert torch.equal(out_idx, out_latent)
     assert torch.equal(out_one, out_latent[1:2])
+
+
+def test_rows_entry_and_fused_adam_equal_the_separate_calls(dev):
+    """reni_forward_loss_backward_rows (the latent gather of RENI_module.py:97-103 inside the prologue kernel) and
+    reni_adam_step2 (decoder + latent-table Adam in one launch) are bit-identical to Z[idx] + the separate calls."""
+    from reni_amd import ops
+    spec = O.DecoderSpec(9, "SO2", 128, 3, 3, True, "tanh")
+    params, Ztab, D, W, T = random_problem(spec, 7, 300, seed=21)
+    idx = torch.tensor([5, 0, 3, 5], device=dev)              # a repeated row: its gradients accumulate, as index_add_ does
+    Tb = T[:4].to(dev)
+    for dtype in ("f32", "bf16"):
+        plan = make_plan(spec, dtype)
+        fp = flat_params(spec, params).to(dev)
+        tab = Ztab.to(dev)
+        a = plan.forward_loss_backward(tab[idx], D.to(dev), fp, Tb, W.to(dev), loss_kind="test", alpha=1e-3, beta=1e-1)
+        b = plan.forward_loss_backward(tab, D.to(dev), fp, Tb, W.to(dev), loss_kind="test", alpha=1e-3, beta=1e-1, idx=idx)
+        assert b[1].shape == (4, 9, 3)
+        for x, y in zip(a[:3], b[:3]):
+            assert torch.equal(x, y)
+        # fused Adam
+        p1, p2, t1, t2 = fp.clone(), fp.clone(), tab.clone(), tab.clone()
+        m1, v1, m2, v2 = (torch.rand_like(fp) * 1e-3 for _ in range(4))
+        m2.copy_(m1); v2.copy_(v1)
+        tm1, tv1 = torch.rand_like(tab) * 1e-3, torch.rand_like(tab) * 1e-3
+        tm2, tv2 = tm1.clone(), tv1.clone()
+        ops.adam_step(p1, a[2], m1, v1, 3, 1e-2, grad_scale=0.5)
+        ops.adam_rows_step(t1, a[1], idx, tm1, tv1, 3, 1e-2, grad_scale=0.5)
+        ops.adam_step2(p2, a[2], m2, v2, t2, a[1], idx, tm2, tv2, 3, 1e-2, grad_scale=0.5)
+        for x, y in ((p1, p2), (m1, m2), (v1, v2), (t1, t2), (tm1, tm2), (tv1, tv2)):
+            assert torch.equal(x, y)
+        assert not torch.equal(t1, tab)
