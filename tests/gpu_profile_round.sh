@@ -1,18 +1,31 @@
 #!/bin/bash
-# usage: gpu_profile_round.sh <tag>  -- GPU test suite, bench line, rocprofv3 kernel stats and HBM-traffic PMC passes
+# usage: gpu_profile_round.sh <tag>  -- bench lines (c2, c4, c5), rocprofv3 kernel stats + step timeline of the same bench
+# command, HBM-traffic PMC passes (separate --pmc runs, no trace domains), instruction-mix / wait counters, and the variants
+# table.  Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
 TAG=$1
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
-python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
-python bench.py > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json
-rocprofv3 --kernel-trace --stats -d $O/kt -o k -- python3 bench.py --steps 10 --warmup 2 > $O/kt.log 2>&1
-python3 profiles/summarize_rocpd.py $O/kt/k_results.db $O/kernel_stats.md > /dev/null 2>&1 || ls -R $O/kt | head
-rocprofv3 --kernel-trace --stats -d $O/ktv -o k -- python3 tests/gpu_prof_variants.py > $O/ktv.log 2>&1
-python3 profiles/summarize_rocpd.py $O/ktv/k_results.db $O/variants_kernel_stats.md > /dev/null 2>&1
+for c in c2 c4 c5; do
+  X=""; [ $c != c2 ] && X="--no-cpu-baseline"
+  python bench.py --config $c $X > $O/bench_$c.json 2>> $O/bench.err; cut -c1-200 $O/bench_$c.json
+done
+for c in c2 c4 c5; do
+  rocprofv3 --kernel-trace --stats -d $O/kt_$c -o k -- python3 bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline > $O/kt_$c.log 2>&1
+  python3 profiles/summarize_rocpd.py $O/kt_$c/k_results.db $O/kernel_stats_$c.md > /dev/null 2>&1 || ls -R $O/kt_$c | head
+  [ $c = c2 ] && python3 profiles/timeline_rocpd.py $O/kt_$c/k_results.db > $O/step_timeline_c2.txt 2>/dev/null
+  rm -rf $O/kt_$c
+done
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o p -- python3 bench.py --steps 3 --warmup 2 > $O/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o p -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $O/pmc_$c.log 2>&1
   python3 profiles/summarize_pmc.py $O/pmc_$c/p_results.db >> $O/pmc_counters.md 2>&1
+  rm -rf $O/pmc_$c
+done
+python3 profiles/make_pmc_traffic.py $O/pmc_counters.md > $O/pmc_traffic.json 2>> $O/bench.err
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_MFMA" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC" "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  tag=$(echo $grp | tr ' ' '_' | cut -c1-60)
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $O/g_$tag -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/g_$tag.log 2>&1
+  python3 profiles/summarize_pmc.py $O/g_$tag/p_results.db 2>&1 | grep -i "train_bf16\|dw1\|^##\|^| kernel\|^|---" >> $O/pmc_instruction_mix.md
+  rm -rf $O/g_$tag $O/g_$tag.log
 done
 python tests/gpu_perf_variants.py > $O/variants.txt 2>&1
-rm -rf $O/kt $O/ktv $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
-head -6 $O/kernel_stats.md; grep train_bf16 $O/pmc_counters.md; tail -12 $O/variants.txt
+head -8 $O/kernel_stats_c2.md; cat $O/pmc_traffic.json; tail -12 $O/variants.txt

@@ -102,3 +102,24 @@ def test_release_library_has_no_result_changing_debug_knobs():
         assert name not in blob, name
     # the two path selectors that remain pick between paths that are both correct (and both tested)
     assert b"RENI_NO_PERSIST" in blob and b"RENI_NO_SIDE_STREAM" in blob
+
+
+def test_counted_wait_in_front_of_the_dA_phase_covers_the_weight_image():
+    """k_reni_train_bf16<128,true> waits `vmcnt(8)` (not 0) for the next tile's first weight image in front of the layer-0
+    dA phase: legal only if the eight newest vector-memory operations at that point are the g_1 stream's stores and every
+    LDS-DMA piece of the image is older.  Checked on every asm `s_waitcnt vmcnt(8)` of the emitted kernel."""
+    text = _isa("core")
+    fn = [x for x in re.split(r"\n\s*\.globl\s+", text) if x.startswith("_ZN4reni17k_reni_train_bf16ILi128ELb1ELb0EEE")][0]
+    lines = [l.strip() for l in fn.split("\n")]
+    sites = [i for i, l in enumerate(lines) if l.startswith("s_waitcnt vmcnt(8)") and "ASMSTART" in lines[i - 1]]
+    assert sites, "the counted wait is gone: update this audit with the code"
+    for i in sites:
+        vm = []
+        for k in range(i - 1, 0, -1):
+            t = lines[k].split(";")[0].strip()
+            if t.startswith(("global_", "scratch_", "buffer_", "flat_")):
+                vm.append(t.split()[0])
+            if len(vm) == 17:
+                break
+        assert vm[:8] == ["global_store_dwordx4"] * 8, vm[:10]
+        assert vm[8:17] == ["global_load_lds_dwordx4"] * 9, vm[8:17]
