@@ -5,7 +5,8 @@ cd reni_amd/csrc
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-spill-vgpr-to-agpr=0 -I../../include"
 i=0; pids=()
 for v in "$@"; do
-  hipcc $FL $v -c reni_tu_core.hip -o _build/core_v$i.o 2>/dev/null &
+  if [ "$v" = "@prev" ]; then cp _build/core_prev.o _build/core_v$i.o &   # a core TU built beforehand from another revision
+  else hipcc $FL $v -c reni_tu_core.hip -o _build/core_v$i.o 2>/dev/null & fi
   pids+=($!); i=$((i+1))
   if [ $((i % 6)) = 0 ]; then for p in "${pids[@]}"; do wait $p; done; pids=(); fi
 done
