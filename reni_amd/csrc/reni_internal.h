@@ -75,6 +75,10 @@ hipError_t launch_main_f32(int H, int mode, const MainArgs& a, int nwg, hipStrea
 hipError_t launch_main_bf16(int H, int mode, const MainArgs& a, int nwg, hipStream_t s);
 hipError_t launch_film_f32(int H, int mode, const MainArgs& a, int nwg, hipStream_t s);
 hipError_t launch_film_bf16(int H, int mode, const MainArgs& a, int nwg, hipStream_t s);
+// FiLM instances of the persistent kernels (reni_tu_train_film.hip): which = 0 training instance, 1 forward / statistics
+hipError_t launch_train_film(int which, const MainArgs& a, int grid, hipStream_t s);
+hipError_t launch_dw1_film(const MainArgs& a, int grid, hipStream_t s);
+int train_film_lds_bytes(int which);
 
 struct PrepArgs {
   const long long* idx;  // optional: image b's latent is row idx[b] of Z (a latent TABLE); the batch's rows are copied to Zc

@@ -15,7 +15,7 @@ cp ../lib/libreni_hip.so ../lib/libreni_hip.so.keep
 for round in 1 2; do
   i=0
   for v in "$@"; do
-    hipcc --offload-arch=gfx950 -shared -fPIC _build/core_v$i.o _build/main_f32.o _build/main_bf16.o _build/film_f32.o _build/film_bf16.o _build/shade.o _build/image.o -o ../lib/libreni_hip.so
+    hipcc --offload-arch=gfx950 -shared -fPIC _build/core_v$i.o _build/main_f32.o _build/main_bf16.o _build/film_f32.o _build/film_bf16.o _build/train_film.o _build/shade.o _build/image.o -o ../lib/libreni_hip.so
     (cd ../..; python bench.py --no-cpu-baseline --steps 30 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-44s' % '$v', 'Msamples/s', round(d['value']/1e6,1), ' step ms', round(d['ms_per_step'],4), ' kernel ms', round(d['roofline']['kernel_avg_ms'],4))")
     i=$((i+1))
   done
