@@ -281,6 +281,21 @@ int reni_unnormalise_srgb(int64_t B, int64_t H, int64_t W, const float* img, con
 int reni_minmax_normalise(int64_t n, const float* img, double minmax0, double minmax1, float* out, void* ws, size_t ws_bytes,
                           void* stream);
 
+/* ---- the data-parallel exchange step over RCCL -------------------------------
+ * Replaces, for the flat decoder gradient, what Lightning's DDP wrapper does in the reference (run.py:97-110:
+ * strategy="ddp" -> NCCL all-reduce of every parameter's gradient, mean over ranks): ONE in-place ncclAllReduce(sum) of
+ * the n floats at `flat`, then flat *= scale (1 / world_size for DDP's mean), both on `stream`.  Latent rows are owned by
+ * one rank each and are never exchanged.
+ * `comm` is an ncclComm_t.  It may come from any RCCL in the process; the three helpers below make one without PyTorch:
+ * rank 0 calls reni_rccl_unique_id and hands the 128 bytes to the other ranks (any side channel), then every rank calls
+ * reni_rccl_comm_create (collective) with its device current.  librccl is loaded on first use: without it these four
+ * return RENI_EUNSUPPORTED and the rest of the library is unaffected. */
+typedef struct { char internal[128]; } reni_rccl_id; /* layout of ncclUniqueId */
+int reni_rccl_unique_id(reni_rccl_id* id);
+int reni_rccl_comm_create(const reni_rccl_id* id, int32_t nranks, int32_t rank, void** comm);
+int reni_rccl_comm_destroy(void* comm);
+int reni_allreduce_grads(void* comm, float* flat, size_t n, float scale, void* stream);
+
 /* Launch geometry chosen for (B,P): workgroups, threads, dynamic LDS bytes (diagnostics). */
 int reni_launch_info(const reni_plan* plan, int64_t B, int64_t P, int32_t* info4);
 

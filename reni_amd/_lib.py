@@ -31,6 +31,7 @@ EXPORTS = (
     "reni_film_model_backward",
     "reni_envmap_shade_workspace_bytes", "reni_envmap_shade", "reni_envmap_shade_backward",
     "reni_image_workspace_bytes", "reni_unnormalise_srgb", "reni_minmax_normalise",
+    "reni_rccl_unique_id", "reni_rccl_comm_create", "reni_rccl_comm_destroy", "reni_allreduce_grads",
 )
 
 
@@ -144,6 +145,14 @@ def load():
     lib.reni_minmax_normalise.argtypes = [c_int64, c_void_p, ctypes.c_double, ctypes.c_double, c_void_p, c_void_p, c_size_t,
                                           c_void_p]
     lib.reni_minmax_normalise.restype = c_int32
+    lib.reni_rccl_unique_id.argtypes = [c_void_p]
+    lib.reni_rccl_unique_id.restype = c_int32
+    lib.reni_rccl_comm_create.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_void_p)]
+    lib.reni_rccl_comm_create.restype = c_int32
+    lib.reni_rccl_comm_destroy.argtypes = [c_void_p]
+    lib.reni_rccl_comm_destroy.restype = c_int32
+    lib.reni_allreduce_grads.argtypes = [c_void_p, c_void_p, c_size_t, c_float, c_void_p]
+    lib.reni_allreduce_grads.restype = c_int32
     _lib = lib
     return lib
 

@@ -4,8 +4,10 @@ Tensors that live on the GPU (a model output on its way to the viewer / the FIT_
 through the HIP epilogue of libreni_hip.so (``reni_unnormalise_srgb`` / ``reni_minmax_normalise``, reni_tu_image.hip).
 Host tensors -- the dataset loader normalises every image once on the CPU, src/data/datasets.py:95-101 -- are mapped by
 the one-line torch expressions below; that is data preparation in front of the path, not the path.
-``transform_builder`` covers the transforms that do not need torchvision (absent here and on the GPU box);
-asking for one that does raises with the transform's name."""
+``transform_builder`` covers the deterministic transforms the reference's configs use (resize, centercrop, to_tensor,
+normalize, minmaxnormalise) with torchvision's tensor semantics restated in torch (torchvision is absent here and on the
+GPU box); the random augmentations, which no shipped config uses, raise with the transform's name."""
+import numpy as np
 import torch
 
 from . import ops
@@ -81,7 +83,69 @@ class UnNormalise(object):
         return tensor.permute(1, 0, 2, 3)
 
 
+class Resize(object):
+    """torchvision.transforms.Resize((h, w)) on a float tensor [..., H, W] as the reference's pinned torchvision 0.11 does it
+    (environment.yml): bilinear ``F.interpolate(..., align_corners=False)`` without antialiasing.  ``size`` is mutable --
+    the datasets' ``double_resolution`` (datasets.py:81-85) doubles it in place."""
+
+    def __init__(self, size):
+        self.size = (int(size[0]), int(size[1]))
+
+    def __call__(self, img):
+        if tuple(img.shape[-2:]) == tuple(self.size):
+            return img
+        x = img if img.dim() == 4 else img[None]
+        y = torch.nn.functional.interpolate(x, size=tuple(self.size), mode="bilinear", align_corners=False)
+        return y if img.dim() == 4 else y[0]
+
+
+class CenterCrop(object):
+    def __init__(self, size):
+        self.size = (int(size), int(size)) if isinstance(size, (int, float)) else (int(size[0]), int(size[1]))
+
+    def __call__(self, img):
+        h, w = img.shape[-2:]
+        th, tw = self.size
+        if th > h or tw > w:
+            raise ValueError(f"CenterCrop {self.size} of a {h} x {w} image")
+        top, left = int(round((h - th) / 2.0)), int(round((w - tw) / 2.0))
+        return img[..., top:top + th, left:left + tw]
+
+
+class ToTensor(object):
+    """[H, W, C] (or [H, W]) array -> [C, H, W] tensor; uint8 is scaled by 1 / 255, float arrays are passed through
+    (torchvision.transforms.ToTensor; the HDR loader feeds it float32, datasets.py:79)."""
+
+    def __call__(self, pic):
+        if isinstance(pic, torch.Tensor):
+            return pic
+        a = np.asarray(pic)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+        return t.to(torch.float32).div(255) if a.dtype == np.uint8 else t
+
+
+class Normalize(object):
+    def __init__(self, mean, std):
+        self.mean, self.std = list(mean), list(std)
+
+    def __call__(self, img):
+        mean = torch.as_tensor(self.mean, dtype=img.dtype, device=img.device).view(-1, 1, 1)
+        std = torch.as_tensor(self.std, dtype=img.dtype, device=img.device).view(-1, 1, 1)
+        return (img - mean) / std
+
+
 def get_transform(transform_name, args):
+    """custom_transforms.py:35-72"""
+    if transform_name == "resize":
+        return Resize((args[0], args[1]))
+    if transform_name == "centercrop":
+        return CenterCrop(args)
+    if transform_name == "to_tensor":
+        return ToTensor()
+    if transform_name == "normalize":
+        return Normalize(args[0], args[1])
     if transform_name == "minmaxnormalise":
         return MinMaxNormalise(args)
     raise NotImplementedError(f"transform {transform_name!r} needs torchvision, which this build does not depend on")

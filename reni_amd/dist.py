@@ -98,6 +98,48 @@ def allreduce_mean_(flat: torch.Tensor):
     return flat
 
 
+class RcclComm:
+    """An RCCL communicator owned by libreni_hip.so, for the one exchange step of the data-parallel path
+    (``reni_allreduce_grads``: in-place sum of the flat decoder gradient + scale, on the caller's stream -- SURVEY 8 (b)
+    item 7).  Rank 0 draws the unique id; it reaches the other ranks through the existing torch.distributed group (any
+    backend -- it is 128 bytes, once).  One process per GPU; the device must be current when this is constructed."""
+
+    def __init__(self, rank=None, world=None):
+        import ctypes
+        from . import _lib
+        self._lib, self._check = _lib.load(), _lib.check
+        self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
+        self.world = world if world is not None else world_size()
+        buf = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            self._check(self._lib.reni_rccl_unique_id(buf))
+        if self.world > 1:
+            box = [buf.raw]
+            dist.broadcast_object_list(box, src=0)
+            buf = ctypes.create_string_buffer(box[0], 128)
+        self._comm = ctypes.c_void_p()
+        self._check(self._lib.reni_rccl_comm_create(buf, self.world, self.rank, ctypes.byref(self._comm)))
+
+    def allreduce_(self, flat: torch.Tensor, scale: float = 1.0):
+        """flat <- scale * sum over ranks of flat, in place, on the current stream"""
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        with torch.cuda.device(flat.device):
+            self._check(self._lib.reni_allreduce_grads(self._comm, flat.data_ptr(), flat.numel(), float(scale),
+                                                       torch.cuda.current_stream(flat.device).cuda_stream))
+        return flat
+
+    def close(self):
+        if getattr(self, "_comm", None) is not None and self._comm:
+            self._check(self._lib.reni_rccl_comm_destroy(self._comm))
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def broadcast_(flat: torch.Tensor, src=0):
     """Replicate rank 0's decoder parameters (what DDP does at wrap time, run.py:110)."""
     if world_size() > 1:

@@ -16,7 +16,11 @@ from . import ops
 
 
 class TrainEngine:
-    def __init__(self, model, lr: float, loss_kind: str = "mse", alpha: float = 0.0, beta: float = 0.0):
+    def __init__(self, model, lr: float, loss_kind: str = "mse", alpha: float = 0.0, beta: float = 0.0, comm=None):
+        """comm: an optional ``dist.RcclComm``; the decoder-gradient all-reduce then goes through the library's own
+        ``reni_allreduce_grads`` on the compute stream instead of torch.distributed's nccl backend (the same RCCL ring
+        either way)."""
+        self.comm = comm
         self.model = model
         self.plan = model._plan()
         self.flat = model._flat_params()
@@ -43,11 +47,16 @@ class TrainEngine:
         inv_w = 1.0 / self.world
         # dense Adam over the whole (owned) latent table, as the reference does (rows outside the
         # batch have zero gradient but still move by momentum -- SURVEY.md Appendix B9)
-        if self.train_decoder and self.world == 1:  # both updates in one launch
+        if self.train_decoder and self.world == 1 and self.comm is None:  # both updates in one launch
             ops.adam_step2(self.flat, dparams, self.m_dec, self.v_dec, self.latent.data, dZ, idx, self.m_lat, self.v_lat,
                            self.t, self.lr, grad_scale=inv_w)
             return terms
         work = None
+        if self.train_decoder and self.comm is not None:  # reni_allreduce_grads: sum + 1 / world on this stream
+            self.comm.allreduce_(dparams, inv_w)
+            ops.adam_rows_step(self.latent.data, dZ, idx, self.m_lat, self.v_lat, self.t, self.lr, grad_scale=inv_w)
+            ops.adam_step(self.flat, dparams, self.m_dec, self.v_dec, self.t, self.lr, grad_scale=1.0)
+            return terms
         if self.train_decoder:  # the one collective of the step; the latent update runs beside it
             work = torch.distributed.all_reduce(dparams, op=torch.distributed.ReduceOp.SUM, async_op=True)
         ops.adam_rows_step(self.latent.data, dZ, idx, self.m_lat, self.v_lat, self.t, self.lr, grad_scale=inv_w)

@@ -11,11 +11,14 @@ build, so the renderer is handed in with ``set_renderer`` (a stored G-buffer, or
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
 from . import dist as rdist
-from .data import SyntheticEnvMapDataset
+from .custom_transforms import transform_builder
+from .data import SyntheticEnvMapDataset, get_dataset
 from .loss_functions import RENITestLoss, RENITestLossInverse, RENITrainLoss, RENIVADTrainLoss
 from .models import get_model
 from .optim import FusedAdam
@@ -230,12 +233,16 @@ class RENI(_Base):
             self.dataset = self._injected_dataset
         else:
             ds = self.config.DATASET
-            if getattr(ds, "NAME", None) != "SYNTHETIC":
-                raise NotImplementedError(
-                    "only DATASET.NAME == 'SYNTHETIC' (or an injected dataset=) is supported: EXR/PNG loading is "
-                    "host I/O outside this build's scope")
-            n = ds.SYNTHETIC.N_TRAIN if self.task == "FIT_DECODER" else ds.SYNTHETIC.N_TEST
-            self.dataset = SyntheticEnvMapDataset(n, img_size[0], img_size[1])
+            name = getattr(ds, "NAME", None)
+            if name == "SYNTHETIC":  # (not in the reference: the stand-in for boxes without the dataset)
+                n = ds.SYNTHETIC.N_TRAIN if self.task == "FIT_DECODER" else ds.SYNTHETIC.N_TEST
+                self.dataset = SyntheticEnvMapDataset(n, img_size[0], img_size[1])
+            else:  # RENI_HDR / RENI_LDR / CUSTOM on disk: resize, then the configured transforms (RENI_module.py:255-281)
+                dcfg = getattr(ds, name)
+                self.is_hdr = dcfg.IS_HDR
+                transforms = transform_builder([["resize", list(img_size)]] + [list(t) for t in dcfg.TRANSFORMS])
+                split = "Train" if self.task == "FIT_DECODER" else "Test"
+                self.dataset = get_dataset(name, dcfg.PATH + os.sep + split, transforms, self.is_hdr)
         self.batch_size = tcfg.BATCH_SIZE
         self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_size=self.batch_size)
 

@@ -231,8 +231,11 @@ def test_hdr_transforms_match_reference(golden):
     np.testing.assert_allclose(utils.sRGB(u.clone()).numpy(), g["srgb1"], rtol=0, atol=1e-6)
     x2 = torch.rand(2, 3, 8, 16, generator=torch.Generator().manual_seed(13)) * 3.0
     np.testing.assert_allclose(utils.sRGB(x2).numpy(), g["srgb2"], rtol=0, atol=1e-6)
+    # resize restates torchvision's tensor path (bilinear, align_corners=False, no antialias); the random augmentations raise
+    r = transform_builder([("resize", [4, 8])])(x2[0])
+    assert torch.equal(r, torch.nn.functional.interpolate(x2[:1], size=(4, 8), mode="bilinear", align_corners=False)[0])
     with pytest.raises(NotImplementedError, match="torchvision"):
-        transform_builder([("resize", [64, 128])])
+        transform_builder([("randomcrop", 8)])
 
 
 def test_envmap_shader_surface():

@@ -141,3 +141,89 @@ def test_bench_two_ranks_over_rccl():
     assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["dist_backend"] == "nccl"
     one = _run_bench({}, "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     assert line["value"] > 1.2 * one["value"]  # weak scaling: two ranks do twice the work per step
+
+
+# ---- reni_allreduce_grads: the library's own RCCL exchange step ----------------------------------
+def _rccl_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        os.environ.pop("RENI_SHARE_GPU", None)
+        os.environ.pop("RENI_DIST_BACKEND", None)
+        from reni_amd import dist as rdist
+        from reni_amd.engine import TrainEngine
+        rdist.init_from_env()  # world 1: no process group at all; world 2: nccl, one GPU per rank
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        comm = rdist.RcclComm(rank, world)
+        x = torch.randn(100003, device=dev, generator=torch.Generator(device=dev).manual_seed(5 + rank))
+        want = sum(torch.randn(100003, device=dev, generator=torch.Generator(device=dev).manual_seed(5 + r)) for r in range(world)) * 0.25
+        comm.allreduce_(x, 0.25)
+        assert float((x - want).abs().max()) <= 1e-6
+        rows = rdist.owned_indices(N_IMG, rank, world)
+        out = {}
+        for native in (True, False):
+            if world > 1 and not native:
+                continue
+            m = _model(len(rows), rows, dev)
+            D, S, T = _data(rows, dev)
+            eng = TrainEngine(m, lr=LR, comm=comm if native else None)
+            idx = torch.arange(len(rows), device=dev)
+            for _ in range(STEPS):
+                eng.step(idx, T, S, D)
+            torch.cuda.synchronize()
+            out[native] = (m._flat_params().detach().cpu().numpy(), m.Z.detach().cpu().numpy())
+        comm.close()
+        q.put((rank, out, rows))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc(), None))
+
+
+def _spawn_rccl(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert not isinstance(r[1], str), r[1]
+    return res
+
+
+def test_rccl_comm_of_one_rank_runs_the_exchange_step():
+    """reni_rccl_unique_id / reni_rccl_comm_create / reni_allreduce_grads / reni_rccl_comm_destroy on the one GPU this box
+    has: a one-rank communicator (the sum over one rank, then the scale kernel), and TrainEngine stepping through it gives
+    bit-for-bit the decoder and latents of the fused single-process update."""
+    (rank, out, rows), = _spawn_rccl(1)
+    assert (out[True][0] == out[False][0]).all() and (out[True][1] == out[False][1]).all()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")
+def test_rccl_comm_two_ranks_equal_the_union_batch():
+    """Two GPUs: the engine's exchange step through reni_allreduce_grads; both ranks end with the same decoder, equal to
+    the single-process step on the union batch with every gradient scaled 1/2."""
+    from reni_amd import ops
+    res = _spawn_rccl(2)
+    f0, f1 = torch.from_numpy(res[0][1][True][0]), torch.from_numpy(res[1][1][True][0])
+    assert torch.equal(f0, f1)
+    dev = torch.device("cuda:0")
+    rows = list(range(N_IMG))
+    m = _model(N_IMG, rows, dev)
+    D, S, T = _data(rows, dev)
+    flat, lat = m._flat_params(), m.Z.data
+    md, vd, ml, vl = torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros_like(lat), torch.zeros_like(lat)
+    idx = torch.arange(N_IMG, device=dev)
+    plan = m._plan()
+    for t in range(1, STEPS + 1):
+        _, dZ, dp, _ = plan.forward_loss_backward(lat[idx], D, flat, T, S, need_dw=True, need_dz=True)
+        ops.adam_rows_step(lat, dZ, idx, ml, vl, t, LR, grad_scale=0.5)
+        ops.adam_step(flat, dp, md, vd, t, LR, grad_scale=0.5)
+    d = (f0 - flat.detach().cpu()).abs()
+    scale = float(flat.abs().max())
+    assert float(torch.quantile(d, 0.5)) <= 1e-6 * scale and float(torch.quantile(d, 0.999)) <= 1e-4 * scale

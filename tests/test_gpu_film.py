@@ -165,11 +165,15 @@ def test_film_full_size_properties(dev):
     assert O.rel_l2(zh.cpu().numpy(), za.cpu().numpy()) <= 3e-2
 
 
-@pytest.mark.parametrize("H,nF", [(128, 3), (256, 2)])
-def test_film_stream_runs_many_small_images(dev, H, nF):
-    """Stream path bookkeeping: more one-tile images than workgroups, so a workgroup's record range covers several
-    images (several runs per workgroup) -- gradients of every parameter and of every latent against the oracle."""
+@pytest.mark.parametrize("H,nF,persist", [(128, 3, True), (128, 3, False), (256, 2, False)])
+def test_film_stream_runs_many_small_images(dev, H, nF, persist, monkeypatch):
+    """Image-run bookkeeping of both bf16 FiLM paths (the persistent kernels at H = 128; the operand-stream path, which
+    RENI_NO_PERSIST selects at H = 128 and H = 256 always uses): more one-tile images than workgroups, so a workgroup's
+    range covers several images (several runs per workgroup) -- gradients of every parameter and of every latent
+    against the oracle."""
     from reni_amd.film import RENIAutoDecoderFiLM
+    if not persist:
+        monkeypatch.setenv("RENI_NO_PERSIST", "1")
     B, P, nd = 700, 96, 4
     spec = O.FilmSpec(nd, "SO2", H, nF, 16, 1, 3, "tanh")
     gen = torch.Generator().manual_seed(11)
@@ -218,3 +222,43 @@ def test_film_core_entry_points_with_caller_owned_glue(dev):
     assert float(dparams[:n_first].abs().max()) == 0.0
     got = dparams[n_first:n_first + m.net[1].layer.weight.numel()].view_as(m.net[1].layer.weight)
     assert O.rel_l2(got.cpu().numpy(), g["g.net.1.layer.weight"]) <= 2e-5
+
+
+@pytest.mark.parametrize("fixed", [False, True])
+def test_film_persistent_runs_cut_inside_workgroup_ranges(dev, fixed, monkeypatch):
+    """FiLM on the persistent kernels (k_reni_train_bf16<.., FILM>, k_reni_dw1<.., FILM>): 5 images of 129 tiles on 256
+    workgroups, so contiguous tile ranges of 2-3 tiles start and end in the middle of images and several cross an image
+    boundary (the accumulators leave the registers there).  Compared with the fp32 kernels (oracle-checked above) and
+    with the operand-stream path on the same inputs; bit-identical from run to run."""
+    from reni_amd.film import RENIAutoDecoderFiLM
+    B, P, nd = 5, 128 * 128 + 77, 6
+    torch.manual_seed(17)
+    m = RENIAutoDecoderFiLM(B, nd, "SO2", 128, 4, 32, 2, 3, "tanh", fixed).to(dev)
+    with torch.no_grad():
+        m.Z.normal_(0, 0.5)
+    gen = torch.Generator().manual_seed(23)
+    D = torch.nn.functional.normalize(torch.randn(1, P, 3, generator=gen), dim=-1).to(dev)
+    S = (torch.rand(1, P, 3, generator=gen) + 0.1).to(dev)
+    T = (torch.rand(B, P, 3, generator=gen) * 2 - 1).to(dev)
+
+    def step(dtype):
+        m.set_compute_dtype(dtype)
+        m.zero_grad(set_to_none=True)
+        Zd = m.Z.detach().clone().requires_grad_(True)
+        terms = m.fused_loss(Zd, D, T, S)
+        terms[0].backward()
+        g = [p.grad.reshape(-1) for k, p in m.named_parameters() if k != "Z" and p.grad is not None]
+        return float(terms[0].detach()), Zd.grad.clone(), (torch.cat(g).clone() if g else None)
+
+    l32, z32, g32 = step("f32")
+    lp, zp, gp = step("bf16")
+    lq, zq, gq = step("bf16")
+    assert lp == lq and torch.equal(zp, zq) and (gp is None or torch.equal(gp, gq))
+    monkeypatch.setenv("RENI_NO_PERSIST", "1")
+    ls, zs, gs = step("bf16")
+    for l_, z_, g_ in ((lp, zp, gp), (ls, zs, gs)):
+        assert abs(l_ - l32) <= 3e-3 * abs(l32)
+        assert O.rel_l2(z_.cpu().numpy(), z32.cpu().numpy()) <= 3e-2
+        if not fixed:
+            assert O.rel_l2(g_.cpu().numpy(), g32.cpu().numpy()) <= 3e-2
+    assert (gp is None) == fixed

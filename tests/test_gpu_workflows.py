@@ -367,3 +367,39 @@ def test_rows_entry_and_fused_adam_equal_the_separate_calls(dev):
         for x, y in ((p1, p2), (m1, m2), (v1, v2), (t1, t2), (tm1, tm2), (tv1, tv2)):
             assert torch.equal(x, y)
         assert not torch.equal(t1, tab)
+
+
+def test_fit_decoder_from_exr_files_on_disk(dev, tmp_path):
+    """SURVEY 8 f3 end to end: a directory of OpenEXR environment maps -> RENIDatasetHDR (reni_amd/exr.py reader, Resize,
+    MinMaxNormalise with the dataset's own log-domain min / max, nan_to_num: src/data/datasets.py:18-101, RENI_module.py:255-281)
+    -> the fused training step with the multi-resolution curriculum -> predictions un-normalised + sRGB on the device."""
+    from reni_amd import exr, trainer
+    from reni_amd.data import RENIDatasetHDR
+    from reni_amd.lightning_module import RENI
+    from reni_amd.utils import sRGB
+    d = tmp_path / "hdr" / "Train"
+    d.mkdir(parents=True)
+    yy, xx = np.meshgrid(np.arange(32), np.arange(64), indexing="ij")
+    for i in range(4):
+        sky = np.exp(2.0 * np.cos(np.pi * yy / 32.0) + 0.3 * i)[:, :, None] * np.array([0.6, 0.8, 1.0])
+        sun = 500.0 * np.exp(-((yy - 6 - i) ** 2 + (xx - 20 - 5 * i) ** 2) / 6.0)[:, :, None]
+        exr.write_exr(str(d / f"env{i + 1}.exr"), (sky + sun).astype(np.float32), pixel_type="half", compression="zip")
+    cfg = _config(LR_START=1e-2, LR_END=1e-3, SCHEDULER_TYPE="exponential", EPOCHS=6, BATCH_SIZE=2,
+                  MULTI_RES_TRAINING=True, INITAL_RESOLUTION=[16, 32], FINAL_RESOLUTION=[32, 64], CURRICULUM=[3])
+    cfg.DATASET = types.SimpleNamespace(NAME="RENI_HDR", RENI_HDR=types.SimpleNamespace(
+        PATH=str(tmp_path / "hdr"), TRANSFORMS=[["minmaxnormalise", []]], IS_HDR=True))
+    torch.manual_seed(0)
+    mod = RENI(cfg, "FIT_DECODER")
+    assert isinstance(mod.dataset, RENIDatasetHDR) and len(mod.dataset) == 4 and mod.dataset.unnormalise is not None
+    img0, i0 = mod.dataset[0]
+    assert img0.shape == (3, 16, 32) and float(img0.min()) >= -1 - 1e-6 and float(img0.max()) <= 1 + 1e-6
+    hist = trainer.fit(mod, max_epochs=6, device=dev)
+    losses = [h["loss"] for h in hist]
+    assert all(np.isfinite(losses)) and losses[2] < losses[0] and losses[-1] < losses[3]
+    assert mod.cur_res == [32, 64] and mod.dataset[0][0].shape == (3, 32, 64)
+    with torch.no_grad():
+        pred = mod.forward(mod.model.Z[:2].detach())                       # [2, P, 3] in the normalised log domain
+    img = pred.view(2, 32, 64, 3).permute(0, 3, 1, 2)
+    lin = mod.dataset.unnormalise(img)                                     # device epilogue (reni_unnormalise_srgb)
+    view = sRGB(lin)
+    assert lin.is_cuda and bool(torch.isfinite(lin).all()) and float(view.min()) >= 0 and float(view.max()) <= 1
