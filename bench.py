@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's headline metric on the fused HIP path.
 
-    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5]
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5|film]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Metric  : directional samples / second (one sample = one (image, direction) pair through encoding -> SIREN ->
@@ -14,6 +14,8 @@ Workload: --config c2 (default, the configuration BASELINE.json's metric is quot
           --config c4 (BASELINE config 4): test-time latent optimisation -- 21 held-out maps, frozen decoder, masked
           RENITestLoss(1e-7, 1e-4) with the cosine term, per-image latent Adam (lr 0.1); one step = statistics pass +
           latent forward/backward + Adam on the latent rows.  No collective (every rank: its own 21 maps).
+          --config film: config 2's training step with the reference's DEFAULT conditioning (configs/default.py:9: FiLM,
+                         5 FiLM layers x 128, mapping network 3 x 128) -- not a BASELINE config, reported beside it.
           --config c5 (BASELINE config 5): fp32 inference at 512x1024 directions, ND = 49, 4 images per step.
           Synthetic images / random-init weights (seed 42).
 Scaling : weak (per-GPU batch fixed; images and their latent rows sharded round-robin over ranks).
@@ -38,6 +40,9 @@ if ROOT not in sys.path:
 
 # algorithmic work per sample, factored form (SURVEY.md 8d / BASELINE.md section 4)
 FLOP_TRAIN, FLOP_FROZEN, FLOP_FWD_ND49 = 522784, 348448, 177860
+# --config film: SURVEY 8(d)'s formulas with L = 4 hidden FiLM layers behind the folded first one (ND = 36, H = 128):
+# F = (ND+2) H + 2 ND + L H^2 + 3 H = 70 856 MAC, Bt = 2 (L H^2 + 3 H) + (ND+2) H + ND H + 2 ND = 141 384 MAC; 2 FLOP / MAC
+FLOP_FILM = 2 * (70856 + 141384)
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # {"<kernel>": {"hbm_bytes_per_launch": .., "src_sha256": ..}}
 
@@ -47,7 +52,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5", "film"])
     ap.add_argument("--batch", type=int, default=None,
                     help="images per GPU per step (c2: 64, <= 615/8 so that 8 ranks can own them; c4: 21; c5: 4)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32"], help="c2 / c4: bf16, c5: f32")
@@ -155,6 +160,11 @@ def main():
         N_IMAGES, H_IMG, W_IMG, ND, B = 615, 128, 256, 36, args.batch or 64
         owned = rdist.owned_indices(N_IMAGES, rank, world)
         model = RENIAutoDecoder(N_IMAGES, ND, "SO2", 128, 5, 3, True, "tanh", 30.0, 30.0, False)
+    elif cfg == "film":
+        from reni_amd.film import RENIAutoDecoderFiLM
+        N_IMAGES, H_IMG, W_IMG, ND, B = 615, 128, 256, 36, args.batch or 64
+        owned = rdist.owned_indices(N_IMAGES, rank, world)
+        model = RENIAutoDecoderFiLM(N_IMAGES, ND, "SO2", 128, 5, 128, 3, 3, "tanh", False)
     elif cfg == "c4":
         N_IMAGES, H_IMG, W_IMG, ND, B = 21, 128, 256, 36, args.batch or 21
         owned = list(range(N_IMAGES))  # every rank optimises its own 21 held-out maps (no shared state, no collective)
@@ -172,7 +182,7 @@ def main():
         model.Z = torch.nn.Parameter(model.Z[owned].clone(), requires_grad=model.Z.requires_grad)
     model.to(dev)
     if world > 1:
-        rdist.broadcast_(model._flat_params(), 0)
+        rdist.broadcast_(model._all_flat() if cfg == "film" else model._flat_params(), 0)
     n_local = len(owned)
     assert n_local >= B, f"per-GPU batch {B} exceeds the {n_local} images this rank owns"
     directions = get_directions(W_IMG).to(dev)
@@ -180,11 +190,11 @@ def main():
     P = directions.shape[1]
     idx_all = torch.arange(n_local, device=dev)  # (the loader's indices: resident like the images)
 
-    if cfg in ("c2", "c4"):
+    if cfg in ("c2", "c4", "film"):
         # this rank's shard of the synthetic set, resident in HBM before the timed region
         ds = SyntheticEnvMapDataset(N_IMAGES, H_IMG, W_IMG)
         imgs = torch.stack([ds.make(i) for i in owned]).to(dev)      # [n_local,3,H,W], ~0.39 MB per image
-        if cfg == "c2":
+        if cfg in ("c2", "film"):
             eng = TrainEngine(model, lr=1e-5)
             weight = sineweight
         else:
@@ -242,6 +252,12 @@ def main():
             kernel = "k_reni_train_bf16<128,true>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD>"
             workload = ("BASELINE config 2: 615-image set, 128x256 equirect, ND=36, 5x128 SIREN, SO2, tanh, AutoDecoder, "
                         "RENITrainLoss; full training step (fwd+loss+bwd, grad all-reduce, Adam)")
+        elif cfg == "film":
+            flop = FLOP_FILM
+            kernel = "k_reni_train_bf16<128,true,false,true>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD,FILM>"
+            workload = ("config 2's set and step with the reference's default conditioning: RENIAutoDecoderFiLM, SO2, ND=36, 5 FiLM "
+                        "layers x 128, mapping network 3 x 128, tanh; full training step (mapping network, fwd+loss+bwd, glue "
+                        "backward, grad all-reduce, Adam over decoder + mapping network + latents)")
         elif cfg == "c4":
             flop = FLOP_FROZEN
             kernel = "k_reni_train_bf16<128,false>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD>"

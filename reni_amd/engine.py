@@ -23,7 +23,9 @@ class TrainEngine:
         self.comm = comm
         self.model = model
         self.plan = model._plan()
-        self.flat = model._flat_params()
+        # FiLM-conditioned models (RENI.py:522-858): the optimised buffer is [net | final_layer | mapping_network]
+        self.film = self.plan.conditioning == "film"
+        self.flat = model._all_flat() if self.film else model._flat_params()
         assert self.flat.is_cuda, "move the model to the GPU first"
         self.latent = model.Z if hasattr(model, "Z") else model.mu
         self.lr = lr
@@ -39,10 +41,18 @@ class TrainEngine:
     def step(self, idx: torch.Tensor, target: torch.Tensor, weight: torch.Tensor, directions: torch.Tensor):
         """idx: rows of this rank's latent table in the batch; target/weight: strided [B,P,3] views.
         Returns the device tensor (loss, mse, prior, cosine) of this rank's batch."""
-        # (the batch's latent rows are gathered inside the prologue kernel: no separate Z[idx] gather)
-        terms, dZ, dparams, _ = self.plan.forward_loss_backward(
-            self.latent.data, directions, self.flat, target, weight, loss_kind=self.loss_kind, alpha=self.alpha,
-            beta=self.beta, need_dw=self.train_decoder, need_dz=True, idx=idx)
+        if self.film:  # mapping network + fused core + glue backward in one library call (reni_film_model_*)
+            n = self.plan.n_params
+            terms, dZ, dparams, _, _ = self.plan.film_model_forward_loss_backward(
+                self.latent.data[idx], directions, self.flat[:n], self.flat[n:], target, weight, loss_kind=self.loss_kind,
+                alpha=self.alpha, beta=self.beta, need_dw=self.train_decoder)
+            if dparams is not None:
+                dparams = dparams._base  # [d params | d map_params]: one buffer, laid out like self.flat
+        else:
+            # (the batch's latent rows are gathered inside the prologue kernel: no separate Z[idx] gather)
+            terms, dZ, dparams, _ = self.plan.forward_loss_backward(
+                self.latent.data, directions, self.flat, target, weight, loss_kind=self.loss_kind, alpha=self.alpha,
+                beta=self.beta, need_dw=self.train_decoder, need_dz=True, idx=idx)
         self.t += 1
         inv_w = 1.0 / self.world
         # dense Adam over the whole (owned) latent table, as the reference does (rows outside the

@@ -227,8 +227,38 @@ class _RENIFiLMBase(_RENIConcatBase):
     def _map_params(self) -> List[nn.Parameter]:
         return list(self.mapping_network.parameters())
 
+    # One flat fp32 buffer holds [net.* | final_layer.* | mapping_network.*]: the `params` and `map_params` arguments of the
+    # reni_film_model_* entry points are its two halves (no per-call concatenation), and an optimiser can step it whole.
+    def _reflatten(self):
+        ps = self._net_params() + (self._map_params() if hasattr(self, "mapping_network") else [])
+        if not ps:
+            return
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1).float() for p in ps])
+            o = 0
+            for p in ps:
+                n = p.numel()
+                p.data = flat[o:o + n].view(p.shape)
+                o += n
+        self._flat_all = flat
+        self._flat = flat[:sum(p.numel() for p in self._net_params())]
+
+    def _all_flat(self) -> torch.Tensor:
+        """[params | map_params], re-flattened if a parameter was re-pointed (``.to(device)``, ``load_state_dict``)"""
+        flat = self._flat_params()
+        base, o = self._flat_all.data_ptr(), flat.numel()
+        ok = self._flat_all.device == flat.device and flat.data_ptr() == base
+        for p in self._map_params():
+            if not ok or p.data_ptr() != base + 4 * o or p.dtype != torch.float32:
+                ok = False
+                break
+            o += p.numel()
+        if not ok:
+            self._reflatten()
+        return self._flat_all
+
     def _map_flat(self) -> torch.Tensor:
-        return torch.cat([p.detach().reshape(-1).float() for p in self._map_params()])
+        return self._all_flat()[self._flat.numel():]
 
     def _split_grads(self, dparams: torch.Tensor, dmap: torch.Tensor):
         out = self._split_flat(dparams)

@@ -280,7 +280,9 @@ class Plan:
 
     def film_model_forward_loss_backward(self, Z, D, params, map_params, target, weight, loss_kind="mse", alpha=0.0,
                                          beta=0.0, need_dw=True, want_out=False):
-        """-> (loss_terms[4], dZ, dparams or None, dmap_params or None, out or None)"""
+        """-> (loss_terms[4], dZ, dparams or None, dmap_params or None, out or None).  The two gradients are the two halves
+        of ONE buffer (dparams first), so an optimiser over [params | map_params] stored the same way takes it whole
+        (``dparams._base``)."""
         _require_cuda(Z, D, params, map_params, target, weight)
         Z = _f32c(Z); params = _f32c(params); map_params = _f32c(map_params)
         self._check_zp(Z, params, map_params)
@@ -297,8 +299,9 @@ class Plan:
         dev = Z.device
         loss_terms = torch.empty(4, dtype=torch.float32, device=dev)
         dZ = torch.empty_like(Z)
-        dparams = torch.empty(self.n_params, dtype=torch.float32, device=dev) if need_dw else None
-        dmap = torch.empty(self.n_map_params, dtype=torch.float32, device=dev) if need_dw else None
+        gall = torch.empty(self.n_params + self.n_map_params, dtype=torch.float32, device=dev) if need_dw else None
+        dparams = gall[:self.n_params] if need_dw else None
+        dmap = gall[self.n_params:] if need_dw else None
         out = torch.empty(B, P, 3, dtype=torch.float32, device=dev) if want_out else None
         ws = self.workspace(B, P, flags, dev)
         wp, wn = self._aligned_ptr(ws)

@@ -262,3 +262,35 @@ def test_film_persistent_runs_cut_inside_workgroup_ranges(dev, fixed, monkeypatc
         if not fixed:
             assert O.rel_l2(g_.cpu().numpy(), g32.cpu().numpy()) <= 3e-2
     assert (gp is None) == fixed
+
+
+def test_film_train_engine_step_equals_autograd_plus_adam(dev):
+    """TrainEngine on a FiLM model (one library call + fused Adam over the flat [net | final_layer | mapping_network] buffer
+    and the latent table) == the same model stepped through fused_loss -> autograd -> torch.optim.Adam over every
+    parameter (RENI_module.py:168-192: Adam over all parameters, dense over the latent table)."""
+    from reni_amd.engine import TrainEngine
+    from reni_amd.film import RENIAutoDecoderFiLM
+    N, P, nd = 6, 300, 5
+    gen = torch.Generator().manual_seed(31)
+    D = torch.nn.functional.normalize(torch.randn(1, P, 3, generator=gen), dim=-1).to(dev)
+    S = (torch.rand(1, P, 3, generator=gen) + 0.1).to(dev)
+    T = (torch.rand(N, P, 3, generator=gen) * 2 - 1).to(dev)
+    models = []
+    for _ in range(2):
+        torch.manual_seed(7)
+        models.append(RENIAutoDecoderFiLM(N, nd, "SO2", 64, 3, 16, 2, 3, "tanh", False).set_compute_dtype("f32").to(dev))
+    a, b = models
+    eng = TrainEngine(a, lr=1e-2)
+    opt = torch.optim.Adam(b.parameters(), lr=1e-2)
+    batches = [torch.tensor([0, 3, 4], device=dev), torch.tensor([5, 1, 1], device=dev)]  # (a repeated row accumulates)
+    for idx in batches:
+        ta = eng.step(idx, T[idx], S, D)
+        opt.zero_grad(set_to_none=True)
+        tb = b.fused_loss(b.Z[idx], D, T[idx], S)
+        tb[0].backward()
+        opt.step()
+        assert abs(float(ta[0]) - float(tb[0].detach())) <= 1e-6 * abs(float(tb[0].detach()))
+    sa, sb = a.state_dict(), b.state_dict()
+    assert set(sa) == set(sb)
+    for k in sa:
+        assert float((sa[k] - sb[k]).abs().max()) <= 2e-6 + 1e-4 * float(sb[k].abs().max()) * 1e-2, k
