@@ -7,7 +7,7 @@ from tests.util import flat_params, make_plan, random_problem
 from reni_amd import ops
 
 dev = torch.device("cuda:0")
-spec = O.DecoderSpec(36, "SO2", 128, 5, 3, True, "tanh")
+spec = O.DecoderSpec(int(os.environ.get("ABL_ND", "36")), "SO2", int(os.environ.get("ABL_H", "128")), 5, 3, True, "tanh")
 B = int(os.environ.get("ABL_B", "64"))
 dtype = os.environ.get("ABL_DTYPE", "bf16")
 params, Z, D, W, T = random_problem(spec, B, 0, seed=2, grid_w=256)
