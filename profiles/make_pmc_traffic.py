@@ -15,8 +15,9 @@ for line in open(sys.argv[1]):
     m = re.match(r"\| `(.+?)` \| (FETCH_SIZE|WRITE_SIZE) \| (\d+) \| ([0-9.e+]+) \|", line)
     if m:
         rows.setdefault(m.group(1), {})[m.group(2)] = float(m.group(4))
-names = {"k_reni_train_bf16<128, true, false>": "k_reni_train_bf16<128,true>",
-         "k_reni_train_bf16<128, false, false>": "k_reni_train_bf16<128,false>"}
+names = {"k_reni_train_bf16<128, true, false, false>": "k_reni_train_bf16<128,true>",
+         "k_reni_train_bf16<128, false, false, false>": "k_reni_train_bf16<128,false>",
+         "k_reni_train_bf16<128, true, false, true>": "k_reni_train_bf16<128,true,false,true>"}
 sha = hashlib.sha256(open(os.path.join(ROOT, "reni_amd", "csrc", "reni_device.inc"), "rb").read()).hexdigest()
 out = {}
 for k, v in rows.items():

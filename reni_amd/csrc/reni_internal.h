@@ -53,7 +53,7 @@ struct MainArgs {
   // stream and k_dw_stream256 finishes dW_l with one layer's accumulator resident in its AGPRs.
   // [L][n_tiles][2 rounds][2 images (g_l | h_{l-1})][256 features][T_ROWB bytes]
   char* dws;
-  // H = 256, concat conditioning: instead of transposed operand images the chain stores what it has in registers -- the
+  // H = 256: instead of transposed operand images the chain stores what it has in registers -- the
   // gradient g_l as bf16 fragments, gfs[(l-1) n_tiles + tile][H/32][2][256 threads][16 B] -- and keeps the phase stash of
   // EVERY tile (stash + tile * stash_per_wg, same fragment layout: h_{l-1} = sin(2 pi phase)); k_dw_frag builds the two
   // operand images of a record in its own LDS.  NULL: the image stream above.

@@ -13,6 +13,7 @@ T = (torch.rand(B, P, 3, device=dev) * 2 - 1)
 idx = torch.arange(B, device=dev)
 for mk in (lambda: RENIAutoDecoder(B, 49, "SO2", 256, 5, 3, True, "tanh", 30, 30, False),
            lambda: RENIAutoDecoderFiLM(B, 36, "SO2", 128, 5, 128, 3, 3, "tanh", False),
+           lambda: RENIAutoDecoderFiLM(B, 49, "SO2", 256, 5, 256, 3, 3, "tanh", False),
            lambda: RENIAutoDecoder(B, 36, "SO2", 128, 5, 3, True, "tanh", 30, 30, True)):
     m = mk()
     if m.fixed_decoder:

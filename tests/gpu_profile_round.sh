@@ -1,24 +1,26 @@
 #!/bin/bash
-# usage: gpu_profile_round.sh <tag>  -- bench lines (c2, c4, c5), rocprofv3 kernel stats + step timeline of the same bench
+# usage: gpu_profile_round.sh <tag>  -- bench lines (c2, c4, c5, film), rocprofv3 kernel stats + step timeline of the same bench
 # command, HBM-traffic PMC passes (separate --pmc runs, no trace domains), instruction-mix / wait counters, and the variants
 # table.  Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
 TAG=$1
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
-for c in c2 c4 c5; do
+for c in c2 c4 c5 film; do
   X=""; [ $c != c2 ] && X="--no-cpu-baseline"
   python bench.py --config $c $X > $O/bench_$c.json 2>> $O/bench.err; cut -c1-200 $O/bench_$c.json
 done
-for c in c2 c4 c5; do
+for c in c2 c4 c5 film; do
   rocprofv3 --kernel-trace --stats -d $O/kt_$c -o k -- python3 bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline > $O/kt_$c.log 2>&1
   python3 profiles/summarize_rocpd.py $O/kt_$c/k_results.db $O/kernel_stats_$c.md > /dev/null 2>&1 || ls -R $O/kt_$c | head
-  [ $c = c2 ] && python3 profiles/timeline_rocpd.py $O/kt_$c/k_results.db > $O/step_timeline_c2.txt 2>/dev/null
+  { [ $c = c2 ] || [ $c = film ]; } && python3 profiles/timeline_rocpd.py $O/kt_$c/k_results.db > $O/step_timeline_$c.txt 2>/dev/null
   rm -rf $O/kt_$c
 done
+for cfg in c2 film; do
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o p -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $O/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o p -- python3 bench.py --config $cfg --steps 3 --warmup 2 --no-cpu-baseline > $O/pmc_$c.log 2>&1
   python3 profiles/summarize_pmc.py $O/pmc_$c/p_results.db >> $O/pmc_counters.md 2>&1
   rm -rf $O/pmc_$c
+done
 done
 python3 profiles/make_pmc_traffic.py $O/pmc_counters.md > $O/pmc_traffic.json 2>> $O/bench.err
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_MFMA" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC" "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
