@@ -95,10 +95,15 @@ int64_t reni_param_count(const reni_plan* plan);
 int32_t reni_in_features(const reni_plan* plan);
 
 /* Bytes of workspace the calls below need for (B images) x (P directions).  `flags` as passed
- * to the call (0 for reni_forward).  Rule of thumb per 128 directions (one tile): 8 KB of partials; plus, for the
- * backward entry points, 32 KB (bf16, H = 128 persistent path: the g_1 stream) or hidden_layers x 70 KB (FiLM, H = 128)
- * / x 144 KB (H = 256) of operand stream on the bf16 stream path (k_dw_stream) -- e.g. 64 images x 32768 directions:
- * 0.8 GB, 5.7 GB, 12 GB.  The stash ring and the per-workgroup gradient partials do not grow with B x P. */
+ * to the call (0 for reni_forward).  It scales with B x P only through per-tile buffers (a tile = 128 directions of one image):
+ *   every backward path            8 KB of per-tile partials (not kept by the bf16 H = 128 training instance: image runs instead)
+ *   bf16, H = 128, L <= 5          32 KB per tile: the g_1 stream (concat and FiLM; FiLM adds one partial slot per image RUN:
+ *                                  <= 3 x #CUs x runs x 0.33 MB, independent of B x P)
+ *   bf16, H = 128, L > 5           hidden_layers x 70 KB per tile: the operand-image stream (k_dw_stream)
+ *   bf16, H = 256                  (2 L + 1) x 64 KB per tile: every tile's phase stash + the g_l fragment stream (k_dw_frag)
+ *   fp32, H = 256, concat          (2 L + 1) x 128 KB per tile: the same in fp32 (k_dw_frag32)
+ * e.g. 64 images x 32768 directions (16 384 tiles): 0.7 GB at 5 x 128, 11 GB at 5 x 256 bf16, 23 GB at 5 x 256 fp32.
+ * The H <= 128 stash ring and the per-workgroup gradient partials do not grow with B x P. */
 size_t reni_workspace_bytes(const reni_plan* plan, int64_t B, int64_t P, uint32_t flags);
 
 /* out[B,P,3] = model(Z, D) under no_grad -- replaces InvariantRepresentation + self.net(x)
