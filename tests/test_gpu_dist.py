@@ -227,3 +227,75 @@ def test_rccl_comm_two_ranks_equal_the_union_batch():
     d = (f0 - flat.detach().cpu()).abs()
     scale = float(flat.abs().max())
     assert float(torch.quantile(d, 0.5)) <= 1e-6 * scale and float(torch.quantile(d, 0.999)) <= 1e-4 * scale
+
+
+# ---- the FiLM TrainEngine under data parallelism: [net | final_layer | mapping_network] is ONE flat buffer and one all-reduce -------
+def _film_model(n_rows, rows, dev):
+    from reni_amd.film import RENIAutoDecoderFiLM
+    torch.manual_seed(0)
+    full = RENIAutoDecoderFiLM(N_IMG, 6, "SO2", 64, 3, 16, 2, 3, "tanh", False)  # (the latent table is drawn before the weights:
+    m = RENIAutoDecoderFiLM(n_rows, 6, "SO2", 64, 3, 16, 2, 3, "tanh", False)    # same table size -> same weights on every rank)
+    for name in ("net", "final_layer", "mapping_network"):
+        getattr(m, name).load_state_dict(getattr(full, name).state_dict())
+    with torch.no_grad():
+        for k, r in enumerate(rows):
+            m.Z[k] = torch.randn(6, 3, generator=torch.Generator().manual_seed(100 + r))
+    return m.set_compute_dtype("f32").to(dev)
+
+
+def _film_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank), RENI_SHARE_GPU="1", RENI_DIST_BACKEND="gloo")
+        from reni_amd import dist as rdist
+        from reni_amd.engine import TrainEngine
+        rdist.init_from_env()
+        dev = torch.device("cuda:0")
+        rows = rdist.owned_indices(N_IMG, rank, world)
+        m = _film_model(len(rows), rows, dev)   # (seed 0 draws the same decoder + mapping network on every rank)
+        D, S, T = _data(rows, dev)
+        eng = TrainEngine(m, lr=LR)
+        idx = torch.arange(len(rows), device=dev)
+        for _ in range(STEPS):
+            eng.step(idx, T, S, D)
+        torch.cuda.synchronize()
+        q.put((rank, m._all_flat().detach().cpu().numpy(), m.Z.detach().cpu().numpy(), rows))
+        torch.distributed.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc(), None, None))
+
+
+def test_film_two_rank_step_equals_one_rank_step_on_the_union_batch():
+    """As the concat test above, for a FiLM model: decoder, head AND mapping network are one flat buffer, all-reduced once."""
+    from reni_amd import ops
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_film_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert not isinstance(r[1], str), r[1]
+    f0, f1 = torch.from_numpy(res[0][1]), torch.from_numpy(res[1][1])
+    assert torch.equal(f0, f1), "ranks ended with different decoders / mapping networks"
+    dev = torch.device("cuda:0")
+    rows = list(range(N_IMG))
+    m = _film_model(N_IMG, rows, dev)
+    D, S, T = _data(rows, dev)
+    flat, lat = m._all_flat(), m.Z.data
+    n = m._plan().n_params
+    md, vd, ml, vl = torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros_like(lat), torch.zeros_like(lat)
+    idx = torch.arange(N_IMG, device=dev)
+    plan = m._plan()
+    for t in range(1, STEPS + 1):
+        _, dZ, dp, _, _ = plan.film_model_forward_loss_backward(lat[idx], D, flat[:n], flat[n:], T, S, need_dw=True)
+        ops.adam_rows_step(lat, dZ, idx, ml, vl, t, LR, grad_scale=0.5)
+        ops.adam_step(flat, dp._base, md, vd, t, LR, grad_scale=0.5)
+    d = (f0 - flat.detach().cpu()).abs()
+    scale = float(flat.abs().max())
+    assert float(torch.quantile(d, 0.5)) <= 1e-6 * scale and float(torch.quantile(d, 0.999)) <= 2e-4 * scale, (float(d.max()), scale)
+    assert float(d.max()) <= 1.1 * LR * STEPS
