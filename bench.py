@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32"], help="c2 / c4: bf16, c5: f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--no-also", action="store_true", help="skip the c4 / c5 / film sub-records of the default (c2) line")
     return ap.parse_args()
 
 
@@ -121,7 +122,7 @@ def cpu_baseline(n_steps):
 
 
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch from the PMC passes (tests/gpu_profile_round.sh), valid only for the kernel sources it
+    """HBM-side bytes per launch from the PMC passes (profiles/tools/gpu_profile_round.sh), valid only for the kernel sources it
     was measured on: the file carries the sha256 of reni_device.inc, and a stale entry reads as null."""
     import hashlib
     try:

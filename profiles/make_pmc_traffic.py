@@ -1,4 +1,4 @@
-"""profiles/pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tests/gpu_profile_round.sh (summarize_pmc.py tables).
+"""profiles/pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of profiles/tools/gpu_profile_round.sh (summarize_pmc.py tables).
 Per dominant kernel: HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB counters; gfx950's FETCH_SIZE tallies 128-B
 read requests at 64 B: MI355X_MICROARCH.md, HBM section), stamped with the sha256 of the kernel sources it was measured on --
 bench.py prints `traffic: null` for any other source state.

@@ -1,6 +1,6 @@
 """Ablation timing of the fused kernel (profiling experiments; numerics are wrong under a mask)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import reni_oracle as O
 from tests.util import flat_params, make_plan, random_problem

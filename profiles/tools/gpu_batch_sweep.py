@@ -1,7 +1,7 @@
 """Diagnostic (not collected by pytest): the config-2 training step (fused fwd + loss + bwd through the module API, no
 optimiser) at the per-GPU batch sizes SURVEY section 8(d) lists."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from reni_amd.models import RENIAutoDecoder
 from reni_amd.utils import get_directions, get_sineweight

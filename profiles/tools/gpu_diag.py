@@ -1,8 +1,8 @@
 """Stage-by-stage GPU diagnostics (prints errors instead of asserting).  Run on the GPU box:
-    python tests/gpu_diag.py
+    python profiles/tools/gpu_diag.py
 """
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 

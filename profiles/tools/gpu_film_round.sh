@@ -4,7 +4,7 @@ cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$1; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_film.py -m gpu -x -q > $O/film.log 2>&1; tail -12 $O/film.log
 D=gpurun_out/_kt_$$
-rocprofv3 --kernel-trace --stats -d $D -o k -- python3 tests/gpu_prof_film.py 64 10 > $O/film_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $D -o k -- python3 profiles/tools/gpu_prof_film.py 64 10 > $O/film_prof.log 2>&1
 tail -2 $O/film_prof.log
 python3 profiles/summarize_rocpd.py $D/k_results.db $O/kernel_stats_film.md > /dev/null 2>&1 || ls -R $D | head
 python3 profiles/timeline_rocpd.py $D/k_results.db > $O/film_timeline.txt 2>/dev/null

@@ -1,7 +1,7 @@
 """Diagnostic (not collected by pytest): one fuzz case in bf16 and fp32 beside the oracle (is a failure a bug or the
 conditioning of a one-sample problem?)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import reni_oracle as O
 from tests.test_gpu_fuzz import _cases

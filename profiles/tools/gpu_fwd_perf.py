@@ -1,6 +1,6 @@
 """Diagnostic (not collected by pytest): bf16 / fp32 inference throughput (reni_forward) at the config-2 shape."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from reni_amd.models import RENIAutoDecoder
 from reni_amd.utils import get_directions

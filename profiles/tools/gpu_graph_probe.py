@@ -1,7 +1,7 @@
 """Diagnostic (not collected by pytest): does a captured hipGraph of the fused fwd+loss+bwd call (prologue, training kernel, k_reni_dw1,
 side-stream chain, reductions) run faster than the same call launched eagerly?  Static inputs, config-2 shape, B = 64."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import reni_oracle as O
 from tests.util import flat_params, make_plan, random_problem

@@ -1,6 +1,6 @@
 """Diagnostic (not collected by pytest): H = 256 gradients vs the oracle, run-to-run determinism."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import reni_oracle as O
 from tests.util import flat_params, make_plan, random_problem, unflatten

@@ -1,6 +1,6 @@
 """Diagnostic (not collected by pytest): fused forward+loss+backward throughput of the non-headline variants."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from reni_amd.models import RENIAutoDecoder
 from reni_amd.film import RENIAutoDecoderFiLM

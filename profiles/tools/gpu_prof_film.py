@@ -1,7 +1,7 @@
 """Diagnostic (not collected by pytest): fused FiLM training steps (SO2, ND 36, 5 x 128, mapping 3 x 128; B images of the
 128 x 256 grid) for rocprofv3 --kernel-trace.  usage: gpu_prof_film.py [B] [steps]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from reni_amd.film import RENIAutoDecoderFiLM
 from reni_amd.utils import get_directions, get_sineweight

@@ -1,6 +1,6 @@
 """Diagnostic (not collected by pytest): a few fused steps of the non-headline variants, for rocprofv3 --kernel-trace."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from reni_amd.film import RENIAutoDecoderFiLM
 from reni_amd.models import RENIAutoDecoder

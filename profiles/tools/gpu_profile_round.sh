@@ -29,5 +29,5 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VM
   python3 profiles/summarize_pmc.py $O/g_$tag/p_results.db 2>&1 | grep -i "train_bf16\|dw1\|^##\|^| kernel\|^|---" >> $O/pmc_instruction_mix.md
   rm -rf $O/g_$tag $O/g_$tag.log
 done
-python tests/gpu_perf_variants.py > $O/variants.txt 2>&1
+python profiles/tools/gpu_perf_variants.py > $O/variants.txt 2>&1
 head -8 $O/kernel_stats_c2.md; cat $O/pmc_traffic.json; tail -12 $O/variants.txt

@@ -1,7 +1,7 @@
 """Diagnostic (not collected by pytest): timing of the environment-map shader at the FIT_INVERSE shapes of
 configs/experiment.yaml (128 x 128 render, batch 3) beside the oracle-shaped torch computation on the host."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import reni_oracle as O
 from reni_amd import ops

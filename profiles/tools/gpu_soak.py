@@ -2,7 +2,7 @@
 300 training steps (k_reni_train_bf16<128,true>) and 300 latent-only steps (k_reni_train_bf16<128,false>), each twice; and
 (round 2) FiLM on the persistent kernels, the H = 256 fragment streams (bf16 concat / FiLM, fp32 concat)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from reni_amd.engine import TrainEngine
 from reni_amd.models import RENIAutoDecoder

@@ -47,7 +47,7 @@ def test_fuzz_against_oracle(c):
         tol["grad"] *= (L + 2) / 6.0  # deeper than any shipped configuration: bf16 rounding compounds per layer (600-case run)
     if c["dtype"] == "bf16" and B * P < 8:
         # A gradient from fewer than eight samples through up to eight sine layers is ill-conditioned: on the one-sample
-        # case of a 600-case run fp32 itself kept 3.5 digits (3e-4) and bf16 none (tests/gpu_fuzz_one.py).  A bf16 gradient
+        # case of a 600-case run fp32 itself kept 3.5 digits (3e-4) and bf16 none (profiles/tools/gpu_fuzz_one.py).  A bf16 gradient
         # comparison would assert nothing there, so these shapes (launch geometry, ragged single tile, masking) are
         # checked through the fp32 kernels instead, at the precision fp32 keeps on them.
         c = dict(c, dtype="f32")
