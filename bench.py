@@ -59,26 +59,55 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-also", action="store_true", help="skip the c4 / c5 / film sub-records of the default (c2) line")
+    ap.add_argument("--comm", default="torch", choices=["torch", "capi"],
+                    help="the step's exchange (decoder-gradient all-reduce): torch.distributed's nccl backend, or the C ABI's "
+                         "reni_allreduce_grads on an RCCL communicator the library owns")
     return ap.parse_args()
 
 
 def spawn_ranks(n):
     """python bench.py --gpus N without a launcher: start N rank processes (children of this one, which has not
-    touched the GPU and never will) with the environment torchrun would give them; rank 0's stdout is ours."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    touched the GPU and never will) with the environment torchrun would give them; rank 0's stdout is ours.
+    The children are polled: the first one to fail takes its siblings down with it (they would otherwise sit in
+    init_process_group / the all-reduce until the process-group timeout), and a failed rendezvous is retried once on
+    a fresh port (the port is picked by bind-and-close, which a concurrent run can win)."""
+    def launch():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        return procs
+
+    for attempt in range(2):
+        procs = launch()
+        t0 = time.time()
+        rc = 0
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                for p in procs:
+                    try:
+                        p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                break
+            if all(c == 0 for c in codes):
+                return 0
+            time.sleep(0.2)
+        if attempt == 0 and time.time() - t0 < 60:  # died at start-up (import, rendezvous): one retry on another port
+            continue
+        return rc
     return rc
 
 
@@ -121,59 +150,72 @@ def cpu_baseline(n_steps):
                       f"encoding + autograd), factored = per-image affine first layer + autograd"}
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch from the PMC passes (profiles/tools/gpu_profile_round.sh), valid only for the kernel sources it
-    was measured on: the file carries the sha256 of reni_device.inc, and a stale entry reads as null."""
+def kernel_src_sha():
+    """sha256 over the kernel sources (reni_amd/csrc/*.inc, *.h, *.hip in name order): profiles/pmc_traffic.json carries it."""
+    import glob
     import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "reni_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.inc")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def pmc_record(kernel):
+    """Counters of one kernel from the PMC passes (profiles/tools/gpu_profile_round.sh -> profiles/pmc_traffic.json): HBM-side
+    bytes per launch and, for the training kernel, the instruction mix.  Valid only for the kernel sources they were measured
+    on: the file carries kernel_src_sha(), and a stale entry reads as nothing (`traffic: null`)."""
     try:
         rec = json.load(open(PMC_TRAFFIC)).get(kernel)
-        src = hashlib.sha256(open(os.path.join(ROOT, "reni_amd", "csrc", "reni_device.inc"), "rb").read()).hexdigest()
-        if rec and rec.get("src_sha256") == src:
-            return rec.get("hbm_bytes_per_launch")
+        if rec and rec.get("src_sha256") == kernel_src_sha():
+            return rec
     except Exception:  # noqa: BLE001
         pass
-    return None
+    return {}
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus))
+def issue_ceiling(valu_per_mfma, trans_per_mfma):
+    """Fraction of the MFMA peak a lone wave per SIMD can reach when it must also issue `valu_per_mfma` VALU instructions
+    (`trans_per_mfma` of them transcendental) per MFMA: slot costs measured on this kernel's exact MFMA form
+    (profiles/r02_mfma_shadow.md: 33.6 cycles per 32x32x16 bf16 MFMA, of which ~13.3 block the issue port; 4.4 cycles a plain
+    VALU, 8.8 a transcendental)."""
+    issue = 13.3 + 4.4 * (valu_per_mfma - trans_per_mfma) + 8.8 * trans_per_mfma
+    return 33.6 / max(33.6, issue)
 
+
+def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None):
+    """One bench configuration in this process: build the model / engine, warm up, time `steps` steps between barriers.
+    Returns the record (value, ms_per_step, roofline ...) on every rank; timing is the MAX over ranks."""
     import torch
     from reni_amd import dist as rdist
-    rank, world, local = rdist.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-
     from reni_amd import ops
     from reni_amd.data import SyntheticEnvMapDataset
     from reni_amd.engine import TrainEngine
     from reni_amd.models import RENIAutoDecoder
     from reni_amd.utils import get_directions, get_sineweight
 
-    cfg = args.config
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
     dtype = args.dtype or ("f32" if cfg == "c5" else "bf16")
     torch.manual_seed(42)
     if cfg == "c2":
-        N_IMAGES, H_IMG, W_IMG, ND, B = 615, 128, 256, 36, args.batch or 64
+        N_IMAGES, H_IMG, W_IMG, ND, B = 615, 128, 256, 36, batch or 64
         owned = rdist.owned_indices(N_IMAGES, rank, world)
         model = RENIAutoDecoder(N_IMAGES, ND, "SO2", 128, 5, 3, True, "tanh", 30.0, 30.0, False)
     elif cfg == "film":
         from reni_amd.film import RENIAutoDecoderFiLM
-        N_IMAGES, H_IMG, W_IMG, ND, B = 615, 128, 256, 36, args.batch or 64
+        N_IMAGES, H_IMG, W_IMG, ND, B = 615, 128, 256, 36, batch or 64
         owned = rdist.owned_indices(N_IMAGES, rank, world)
         model = RENIAutoDecoderFiLM(N_IMAGES, ND, "SO2", 128, 5, 128, 3, 3, "tanh", False)
     elif cfg == "c4":
-        N_IMAGES, H_IMG, W_IMG, ND, B = 21, 128, 256, 36, args.batch or 21
+        N_IMAGES, H_IMG, W_IMG, ND, B = 21, 128, 256, 36, batch or 21
         owned = list(range(N_IMAGES))  # every rank optimises its own 21 held-out maps (no shared state, no collective)
         model = RENIAutoDecoder(N_IMAGES, ND, "SO2", 128, 5, 3, True, "tanh", 30.0, 30.0, True)
         with torch.no_grad():
             model.Z.normal_()  # (fixed_decoder starts the latents at zero; any start costs the same)
     else:
-        N_IMAGES, H_IMG, W_IMG, ND, B = 4, 512, 1024, 49, args.batch or 4
+        N_IMAGES, H_IMG, W_IMG, ND, B = 4, 512, 1024, 49, batch or 4
         owned = list(range(N_IMAGES))
         model = RENIAutoDecoder(N_IMAGES, ND, "SO2", 128, 5, 3, True, "tanh", 30.0, 30.0, True)
         with torch.no_grad():
@@ -195,8 +237,11 @@ def main():
         # this rank's shard of the synthetic set, resident in HBM before the timed region
         ds = SyntheticEnvMapDataset(N_IMAGES, H_IMG, W_IMG)
         imgs = torch.stack([ds.make(i) for i in owned]).to(dev)      # [n_local,3,H,W], ~0.39 MB per image
+        comm = None
+        if args.comm == "capi" and cfg in ("c2", "film"):  # the exchange step through the C ABI's reni_allreduce_grads
+            comm = rdist.RcclComm(rank, world)
         if cfg in ("c2", "film"):
-            eng = TrainEngine(model, lr=1e-5)
+            eng = TrainEngine(model, lr=1e-5, comm=comm)
             weight = sineweight
         else:
             # inpainting mask of the notebook's kind (examples.ipynb cell 4, Mask-3: 18.8 % of the pixels kept): a
@@ -220,17 +265,15 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if world > 1:  # create the RCCL communicator outside the timed region even with --warmup 0
-        torch.distributed.all_reduce(torch.zeros(1, device=dev))
-    for s in range(args.warmup):
+    for s in range(warmup):
         step(s)
     barrier()
     ops.profile_enable(True)
     ops.profile_read(reset=True, kind=ops.PROF_ALL)
     t0 = time.perf_counter()
     last = None
-    for s in range(args.steps):
-        last = step(args.warmup + s)
+    for s in range(steps):
+        last = step(warmup + s)
     barrier()
     dt = time.perf_counter() - t0
     kind = ops.PROF_FWD if cfg == "c5" else ops.PROF_FWD_BWD
@@ -244,48 +287,94 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax)
-    value = world * B * P * args.steps / dt
+    value = world * B * P * steps / dt
 
+    kavg_ms = kern_ms / max(kern_n, 1)
+    if cfg == "c2":
+        flop = FLOP_TRAIN
+        kernel = "k_reni_train_bf16<128,true>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD>"
+        workload = ("BASELINE config 2: 615-image set, 128x256 equirect, ND=36, 5x128 SIREN, SO2, tanh, AutoDecoder, "
+                    "RENITrainLoss; full training step (fwd+loss+bwd, grad all-reduce, Adam)")
+    elif cfg == "film":
+        flop = FLOP_FILM
+        kernel = "k_reni_train_bf16<128,true,false,true>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD,FILM>"
+        workload = ("config 2's set and step with the reference's default conditioning: RENIAutoDecoderFiLM, SO2, ND=36, 5 FiLM "
+                    "layers x 128, mapping network 3 x 128, tanh; full training step (mapping network, fwd+loss+bwd, glue "
+                    "backward, grad all-reduce, Adam over decoder + mapping network + latents)")
+    elif cfg == "c4":
+        flop = FLOP_FROZEN
+        kernel = "k_reni_train_bf16<128,false>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD>"
+        workload = ("BASELINE config 4: test-time latent optimisation, 21 held-out maps, 128x256 equirect, ND=36, 5x128 SIREN, "
+                    "frozen decoder, masked (18.8 % kept) RENITestLoss(1e-7,1e-4) with the cosine term, per-image latent "
+                    "Adam lr 0.1; full step (statistics pass + latent fwd/bwd + Adam)")
+    else:
+        flop = FLOP_FWD_ND49
+        kernel = "k_reni_main<f32,H=128,FWD>" if dtype == "f32" else "k_reni_train_bf16<128,false,true>"
+        workload = "BASELINE config 5: inference, 512x1024 directions, ND=49, 5x128 SIREN, SO2, 4 images per step"
+    achieved = B * P * flop / (kavg_ms * 1e-3) / 1e12
+    pmc = pmc_record(kernel)
+    roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+            "frac": achieved / PEAK_TFLOPS[dtype], "traffic": pmc.get("hbm_bytes_per_launch"), "kernel": kernel,
+            "kernel_avg_ms": kavg_ms, "kernel_launches": kern_n, "flop_per_sample": flop}
+    if pmc.get("valu_per_mfma"):
+        # the co-bound: one wave per SIMD issues the SIREN's activation / epilogue VALU through the same port as its
+        # MFMAs; `issue_limited_frac` is the MFMA-peak fraction that instruction mix allows even with perfect overlap
+        vpm, tpm = pmc["valu_per_mfma"], pmc.get("trans_per_mfma", 2.1)
+        roof.update({"bound": "mfma+valu_issue", "valu_per_mfma": vpm, "trans_per_mfma": tpm,
+                     "issue_limited_frac": issue_ceiling(vpm, tpm), "frac_of_issue_limit": roof["frac"] / issue_ceiling(vpm, tpm)})
+    if stats_n:
+        roof["stats_pass_avg_ms"] = stats_ms / stats_n
+    rec = {"value": value, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": dtype,
+           "config": {"workload": workload, "images_per_gpu_per_step": B, "global_batch_images": world * B,
+                      "directions_per_image": P, "parallelism": f"dp{world}", "result_check": check},
+           "roofline": roof}
+    if args.comm == "capi":
+        rec["config"]["exchange_step"] = "reni_allreduce_grads (C ABI, librccl)"
+    del model
+    torch.cuda.empty_cache()
+    return rec
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
+    import torch
+    from reni_amd import dist as rdist
+    rank, world, local = rdist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:  # create the RCCL communicator outside the timed region even with --warmup 0
+        torch.distributed.all_reduce(torch.zeros(1, device=dev))
+
+    cfg = args.config
+    rec = run_config(cfg, args, rank, world, dev, batch=args.batch)
+    line = {
+        "metric": "directional-samples/sec (fwd+bwd), 128x256 equirect, ND=36 latent" if cfg != "c5"
+                  else "directional-samples/sec (fwd), 512x1024 equirect, ND=49 latent",
+        "value": rec["value"], "unit": "samples/s", "n_gpus": world, "steps": rec["steps"], "warmup": rec["warmup"],
+        "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic",
+        "n_ranks_seen": torch.distributed.get_world_size() if world > 1 else 1,
+        "dist_backend": torch.distributed.get_backend() if world > 1 else None,
+        "config": rec["config"], "roofline": rec["roofline"],
+    }
+    if cfg == "c2" and world == 1 and not args.no_also:
+        # the other BASELINE configurations (and the reference's default conditioning) measured in the same process, 20 steps each:
+        # sub-records beside the headline line, each with its own ms_per_step / roofline
+        also = {}
+        for c in ("c4", "c5", "film"):
+            args.dtype = None
+            r = run_config(c, args, rank, world, dev, steps=20, warmup=3)
+            also[c] = {"metric": "directional-samples/sec (fwd), 512x1024 equirect, ND=49 latent" if c == "c5" else line["metric"],
+                       "value": r["value"], "unit": "samples/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                       "dtype": r["dtype"], "workload": r["config"]["workload"],
+                       "images_per_gpu_per_step": r["config"]["images_per_gpu_per_step"], "roofline": r["roofline"]}
+        line["also"] = also
     if rank == 0:
-        kavg_ms = kern_ms / max(kern_n, 1)
-        if cfg == "c2":
-            flop = FLOP_TRAIN
-            kernel = "k_reni_train_bf16<128,true>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD>"
-            workload = ("BASELINE config 2: 615-image set, 128x256 equirect, ND=36, 5x128 SIREN, SO2, tanh, AutoDecoder, "
-                        "RENITrainLoss; full training step (fwd+loss+bwd, grad all-reduce, Adam)")
-        elif cfg == "film":
-            flop = FLOP_FILM
-            kernel = "k_reni_train_bf16<128,true,false,true>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD,FILM>"
-            workload = ("config 2's set and step with the reference's default conditioning: RENIAutoDecoderFiLM, SO2, ND=36, 5 FiLM "
-                        "layers x 128, mapping network 3 x 128, tanh; full training step (mapping network, fwd+loss+bwd, glue "
-                        "backward, grad all-reduce, Adam over decoder + mapping network + latents)")
-        elif cfg == "c4":
-            flop = FLOP_FROZEN
-            kernel = "k_reni_train_bf16<128,false>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD>"
-            workload = ("BASELINE config 4: test-time latent optimisation, 21 held-out maps, 128x256 equirect, ND=36, 5x128 SIREN, "
-                        "frozen decoder, masked (18.8 % kept) RENITestLoss(1e-7,1e-4) with the cosine term, per-image latent "
-                        "Adam lr 0.1; full step (statistics pass + latent fwd/bwd + Adam)")
-        else:
-            flop = FLOP_FWD_ND49
-            kernel = "k_reni_main<f32,H=128,FWD>" if dtype == "f32" else "k_reni_train_bf16<128,false,true>"
-            workload = "BASELINE config 5: inference, 512x1024 directions, ND=49, 5x128 SIREN, SO2, 4 images per step"
-        achieved = B * P * flop / (kavg_ms * 1e-3) / 1e12
-        line = {
-            "metric": "directional-samples/sec (fwd+bwd), 128x256 equirect, ND=36 latent" if cfg != "c5"
-                      else "directional-samples/sec (fwd), 512x1024 equirect, ND=49 latent",
-            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "n_ranks_seen": torch.distributed.get_world_size() if world > 1 else 1,
-            "dist_backend": torch.distributed.get_backend() if world > 1 else None,
-            "config": {"workload": workload, "images_per_gpu_per_step": B, "global_batch_images": world * B,
-                       "directions_per_image": P, "parallelism": f"dp{world}", "result_check": check},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_TFLOPS[dtype], "traffic": pmc_traffic(kernel), "kernel": kernel,
-                         "kernel_avg_ms": kavg_ms, "kernel_launches": kern_n, "flop_per_sample": flop},
-        }
-        if stats_n:
-            line["roofline"]["stats_pass_avg_ms"] = stats_ms / stats_n
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_steps)
         print(json.dumps(line), flush=True)

@@ -1,29 +1,40 @@
-"""profiles/pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of profiles/tools/gpu_profile_round.sh (summarize_pmc.py tables).
+"""profiles/pmc_traffic.json from the PMC passes of profiles/tools/gpu_profile_round.sh (summarize_pmc.py tables).
 Per dominant kernel: HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB counters; gfx950's FETCH_SIZE tallies 128-B
-read requests at 64 B: MI355X_MICROARCH.md, HBM section), stamped with the sha256 of the kernel sources it was measured on --
+read requests at 64 B: MI355X_MICROARCH.md, HBM section) and, where the instruction-mix passes saw the kernel, VALU /
+transcendental instructions per MFMA -- stamped with bench.kernel_src_sha() of the kernel sources it was measured on:
 bench.py prints `traffic: null` for any other source state.
-usage: python profiles/make_pmc_traffic.py <pmc_counters.md>"""
-import hashlib
+usage: python profiles/make_pmc_traffic.py <pmc_counters.md> [<pmc_instruction_mix.md>]"""
 import json
 import os
 import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_src_sha  # noqa: E402
+
 rows = {}
-for line in open(sys.argv[1]):
-    m = re.match(r"\| `(.+?)` \| (FETCH_SIZE|WRITE_SIZE) \| (\d+) \| ([0-9.e+]+) \|", line)
-    if m:
-        rows.setdefault(m.group(1), {})[m.group(2)] = float(m.group(4))
+for path in sys.argv[1:]:
+    for line in open(path):
+        m = re.match(r"\| `(.+?)` \| ([A-Z_0-9]+) \| (\d+) \| ([0-9.e+]+) \|", line)
+        if m:
+            rows.setdefault(m.group(1), {})[m.group(2)] = float(m.group(4))
 names = {"k_reni_train_bf16<128, true, false, false>": "k_reni_train_bf16<128,true>",
          "k_reni_train_bf16<128, false, false, false>": "k_reni_train_bf16<128,false>",
-         "k_reni_train_bf16<128, true, false, true>": "k_reni_train_bf16<128,true,false,true>"}
-sha = hashlib.sha256(open(os.path.join(ROOT, "reni_amd", "csrc", "reni_device.inc"), "rb").read()).hexdigest()
+         "k_reni_train_bf16<128, false, true, false>": "k_reni_train_bf16<128,false,true>",
+         "k_reni_train_bf16<128, true, false, true>": "k_reni_train_bf16<128,true,false,true>",
+         "k_reni_main<reni::PolF32, 128, 0, false>": "k_reni_main<f32,H=128,FWD>"}
+sha = kernel_src_sha()
 out = {}
 for k, v in rows.items():
     for frag, nice in names.items():
         if frag in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            out[nice] = {"hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), "FETCH_SIZE_KB": v["FETCH_SIZE"],
-                         "WRITE_SIZE_KB": v["WRITE_SIZE"], "src_sha256": sha,
-                         "note": "2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes of bench.py --steps 3; L2 <-> fabric bytes, Infinity-Cache hits included"}
+            rec = {"hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), "FETCH_SIZE_KB": v["FETCH_SIZE"],
+                   "WRITE_SIZE_KB": v["WRITE_SIZE"], "src_sha256": sha,
+                   "note": "2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes of bench.py --steps 3; L2 <-> fabric bytes, Infinity-Cache hits included"}
+            if "SQ_INSTS_VALU" in v and "SQ_INSTS_MFMA" in v:  # (SQ_INSTS_VALU counts the MFMAs too)
+                rec["valu_per_mfma"] = round((v["SQ_INSTS_VALU"] - v["SQ_INSTS_MFMA"]) / v["SQ_INSTS_MFMA"], 3)
+                if "SQ_INSTS_VALU_TRANS" in v:
+                    rec["trans_per_mfma"] = round(v["SQ_INSTS_VALU_TRANS"] / v["SQ_INSTS_MFMA"], 3)
+            out[nice] = rec
 print(json.dumps(out, indent=1))

@@ -1,3 +1,1 @@
-TAILN=300 profiles/tools/gpu_variants.sh --rounds 1 --cmd "python profiles/tools/gpu_trace.py" "-DRENI_TRACE" > gpurun_out/r03_trace12.txt 2>&1
-profiles/tools/gpu_variants.sh --rounds 2 "@base" > gpurun_out/r03_b12.txt 2>&1; cat gpurun_out/r03_b12.txt
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+TAILN=300 profiles/tools/gpu_variants.sh --rounds 1 --cmd "python profiles/tools/gpu_trace.py" "-DRENI_TRACE" "-DRENI_TRACE -DRENI_EXP=524288" > gpurun_out/r03_trace13.txt 2>&1

@@ -1,33 +1,35 @@
 #!/bin/bash
-# usage: gpu_profile_round.sh <tag>  -- bench lines (c2, c4, c5, film), rocprofv3 kernel stats + step timeline of the same bench
-# command, HBM-traffic PMC passes (separate --pmc runs, no trace domains), instruction-mix / wait counters, and the variants
-# table.  Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
+# usage: gpu_profile_round.sh <tag>  -- bench lines (c2 with its sub-records, c4, c5, film), rocprofv3 kernel stats + step timeline of
+# the same bench command, HBM-traffic PMC passes for every dominant kernel (separate --pmc runs, no trace domains), instruction-mix /
+# wait counters, and the variants table.  Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
 TAG=$1
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
+rm -f $O/pmc_counters.md $O/pmc_instruction_mix.md
 for c in c2 c4 c5 film; do
-  X=""; [ $c != c2 ] && X="--no-cpu-baseline"
+  for cnt in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $cnt --kernel-trace -d $O/pmc_$cnt -o p -- python3 bench.py --config $c --steps 3 --warmup 2 --no-cpu-baseline --no-also > $O/pmc_$cnt.log 2>&1
+    python3 profiles/summarize_pmc.py $O/pmc_$cnt/p_results.db >> $O/pmc_counters.md 2>&1
+    rm -rf $O/pmc_$cnt
+  done
+done
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_MFMA" "SQ_INSTS_VALU_TRANS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC" "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  tag=$(echo $grp | tr ' ' '_' | cut -c1-60)
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $O/g_$tag -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also > $O/g_$tag.log 2>&1
+  python3 profiles/summarize_pmc.py $O/g_$tag/p_results.db 2>&1 | grep -i "train_bf16\|dw1\|^##\|^| kernel\|^|---" >> $O/pmc_instruction_mix.md
+  rm -rf $O/g_$tag $O/g_$tag.log
+done
+python3 profiles/make_pmc_traffic.py $O/pmc_counters.md $O/pmc_instruction_mix.md > $O/pmc_traffic.json 2>> $O/bench.err
+cp $O/pmc_traffic.json profiles/pmc_traffic.json   # (so that the bench lines below carry the traffic of THIS source state)
+for c in c2 c4 c5 film; do
+  X="--no-cpu-baseline"; [ $c = c2 ] && X=""
   python bench.py --config $c $X > $O/bench_$c.json 2>> $O/bench.err; cut -c1-200 $O/bench_$c.json
 done
 for c in c2 c4 c5 film; do
-  rocprofv3 --kernel-trace --stats -d $O/kt_$c -o k -- python3 bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline > $O/kt_$c.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/kt_$c -o k -- python3 bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline --no-also > $O/kt_$c.log 2>&1
   python3 profiles/summarize_rocpd.py $O/kt_$c/k_results.db $O/kernel_stats_$c.md > /dev/null 2>&1 || ls -R $O/kt_$c | head
   { [ $c = c2 ] || [ $c = film ]; } && python3 profiles/timeline_rocpd.py $O/kt_$c/k_results.db > $O/step_timeline_$c.txt 2>/dev/null
   rm -rf $O/kt_$c
-done
-for cfg in c2 film; do
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o p -- python3 bench.py --config $cfg --steps 3 --warmup 2 --no-cpu-baseline > $O/pmc_$c.log 2>&1
-  python3 profiles/summarize_pmc.py $O/pmc_$c/p_results.db >> $O/pmc_counters.md 2>&1
-  rm -rf $O/pmc_$c
-done
-done
-python3 profiles/make_pmc_traffic.py $O/pmc_counters.md > $O/pmc_traffic.json 2>> $O/bench.err
-for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_MFMA" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC" "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
-  tag=$(echo $grp | tr ' ' '_' | cut -c1-60)
-  timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $O/g_$tag -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/g_$tag.log 2>&1
-  python3 profiles/summarize_pmc.py $O/g_$tag/p_results.db 2>&1 | grep -i "train_bf16\|dw1\|^##\|^| kernel\|^|---" >> $O/pmc_instruction_mix.md
-  rm -rf $O/g_$tag $O/g_$tag.log
 done
 python profiles/tools/gpu_perf_variants.py > $O/variants.txt 2>&1
 head -8 $O/kernel_stats_c2.md; cat $O/pmc_traffic.json; tail -12 $O/variants.txt

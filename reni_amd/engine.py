@@ -55,22 +55,22 @@ class TrainEngine:
                 beta=self.beta, need_dw=self.train_decoder, need_dz=True, idx=idx)
         self.t += 1
         inv_w = 1.0 / self.world
-        # dense Adam over the whole (owned) latent table, as the reference does (rows outside the
-        # batch have zero gradient but still move by momentum -- SURVEY.md Appendix B9)
-        if self.train_decoder and self.world == 1 and self.comm is None:  # both updates in one launch
+        # ONE exchange step: the in-place sum of the flat decoder gradient over the ranks (run.py:97's DDP all-reduce; the 1 / world
+        # of its mean rides on Adam's grad_scale).  Either the library's own reni_allreduce_grads on this stream (comm=) or
+        # torch.distributed's nccl backend, which orders itself against this stream on the device -- no host wait either way.
+        # Latent rows need no communication (dist.py).  FIT_LATENT (frozen decoder): no collective at all.
+        if self.train_decoder and self.world > 1:
+            if self.comm is not None:
+                self.comm.allreduce_(dparams, 1.0)
+            else:
+                torch.distributed.all_reduce(dparams, op=torch.distributed.ReduceOp.SUM)
+        elif self.train_decoder and self.comm is not None:  # (a one-rank communicator: the same call path, for tests)
+            self.comm.allreduce_(dparams, 1.0)
+        # dense Adam over the whole (owned) latent table, as the reference does (rows outside the batch have zero gradient but
+        # still move by momentum -- SURVEY.md Appendix B9); decoder and latent table in ONE launch (reni_adam_step2), as at N = 1
+        if self.train_decoder:
             ops.adam_step2(self.flat, dparams, self.m_dec, self.v_dec, self.latent.data, dZ, idx, self.m_lat, self.v_lat,
                            self.t, self.lr, grad_scale=inv_w)
-            return terms
-        work = None
-        if self.train_decoder and self.comm is not None:  # reni_allreduce_grads: sum + 1 / world on this stream
-            self.comm.allreduce_(dparams, inv_w)
+        else:
             ops.adam_rows_step(self.latent.data, dZ, idx, self.m_lat, self.v_lat, self.t, self.lr, grad_scale=inv_w)
-            ops.adam_step(self.flat, dparams, self.m_dec, self.v_dec, self.t, self.lr, grad_scale=1.0)
-            return terms
-        if self.train_decoder:  # the one collective of the step; the latent update runs beside it
-            work = torch.distributed.all_reduce(dparams, op=torch.distributed.ReduceOp.SUM, async_op=True)
-        ops.adam_rows_step(self.latent.data, dZ, idx, self.m_lat, self.v_lat, self.t, self.lr, grad_scale=inv_w)
-        if self.train_decoder:
-            work.wait()
-            ops.adam_step(self.flat, dparams, self.m_dec, self.v_dec, self.t, self.lr, grad_scale=inv_w)
         return terms
