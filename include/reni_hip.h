@@ -135,8 +135,10 @@ int reni_forward_loss_backward(const reni_plan* plan, int64_t B, int64_t P, cons
 
 /* The same with the batch's latents given as ROWS OF A TABLE: image b uses Z_table[idx[b]] ([n_rows][ndims][3], idx on the
  * device) -- `Z = self.model.Z[idx, :, :]` of the training step (RENI_module.py:97-103) happens inside the prologue kernel
- * instead of as a separate gather.  dZ is [B][ndims][3] in batch order, as above. */
-int reni_forward_loss_backward_rows(const reni_plan* plan, int64_t B, int64_t P, const float* Z_table, const int64_t* idx,
+ * instead of as a separate gather.  dZ is [B][ndims][3] in batch order, as above.  An idx[b] outside [0, n_rows) cannot be
+ * reported without a host synchronisation: it reads no memory outside the table, and image b's outputs, the loss terms and
+ * every gradient of the call come out NaN (the reference's `Z[idx]` raises a device-side assert). */
+int reni_forward_loss_backward_rows(const reni_plan* plan, int64_t B, int64_t P, const float* Z_table, int64_t n_rows, const int64_t* idx,
                                     const float* D, int64_t d_batch_stride, const float* params, const float* target,
                                     const int64_t target_strides[3], const float* weight, const int64_t weight_strides[3],
                                     int32_t loss_kind, float alpha, float beta, uint32_t flags, float* out,

@@ -83,7 +83,7 @@ def load():
         c_int32, c_float, c_float, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.reni_forward_loss_backward.restype = c_int32
     lib.reni_forward_loss_backward_rows.argtypes = [
-        c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, i64x3, c_void_p, i64x3,
+        c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, i64x3, c_void_p, i64x3,
         c_int32, c_float, c_float, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.reni_forward_loss_backward_rows.restype = c_int32
     lib.reni_adam_step2.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,

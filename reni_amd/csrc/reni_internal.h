@@ -87,6 +87,7 @@ int train_film_lds_bytes(int which);
 
 struct PrepArgs {
   const long long* idx;  // optional: image b's latent is row idx[b] of Z (a latent TABLE); the batch's rows are copied to Zc
+  long long n_rows;      // rows of that table: an index outside [0, n_rows) poisons the image's results with NaN
   float* Zc;             // [B][nd][3] compact copy of the gathered rows (read by the epilogue kernels), with idx only
   const float* Z;
   const float* W0;

@@ -79,8 +79,22 @@ __global__ void __launch_bounds__(256) k_img_quantile(const float* in, int n, lo
   __shared__ float pick[2];
   const int o = blockIdx.x;
   const float* base = in + (long long)(o / inner) * outer_stride + (long long)(o % inner) * inner_stride;
-  for (int i = threadIdx.x; i < n; i += 256) v[i] = base[(long long)i * es];
+  // (a NaN in the column: every comparison below is false, ranks collide and a pick may never be written -- torch.quantile
+  // propagates NaN, and so does this: the picks start as NaN and a column holding one keeps them)
+  if (threadIdx.x < 2) pick[threadIdx.x] = __builtin_nanf("");
+  __shared__ int has_nan;
+  if (threadIdx.x == 0) has_nan = 0;
   __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float x = base[(long long)i * es];
+    v[i] = x;
+    if (x != x) has_nan = 1;
+  }
+  __syncthreads();
+  if (has_nan) {
+    if (threadIdx.x == 0) out[o] = __builtin_nanf("");
+    return;
+  }
   const float rank = qf * (float)(n - 1);
   const float fl = floorf(rank);
   const int lo = (int)fl, hi = (int)ceilf(rank);
@@ -135,7 +149,8 @@ __global__ void __launch_bounds__(256) k_img_normalise(const float* in, long lon
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float lo = __uint_as_float(mm[0]), hi = __uint_as_float(mm[1]);
-  const float x = fminf(fmaxf(in[i], lo), hi);  // torch.clip: min(max(x, lo), hi)
+  const float xi = in[i];
+  const float x = (xi != xi) ? xi : fminf(fmaxf(xi, lo), hi);  // torch.clip: min(max(x, lo), hi), NaN stays NaN (fmaxf would drop it)
   out[i] = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, __fsub_rn(logf(x), m0)), range), 1.f);  // 2 * (log x - m0) / (m1 - m0) - 1
 }
 

@@ -10,8 +10,9 @@ family: byte-interleave + delta predictor + deflate) and PIZ (wavelet + Huffman,
 files and the lossy codecs (PXR24, B44, DWA) raise ``NotImplementedError`` naming what was found.
 ``write_exr`` (NONE / RLE / ZIPS / ZIP, half or float) is used to save predictions and to make the test fixtures.
 
-Parity note: no EXR file and no EXR library exists in the build image, so this module is pinned by hand-assembled
-known-answer files in tests/test_exr_cpu.py, not by a file the reference's own loader has read.
+EXR reader: PARITY UNPINNED.  No EXR file and no EXR library exists in the build image, so this module is checked only
+against hand-assembled known-answer files in tests/test_exr_cpu.py and round trips through its own writer -- not against a
+file the reference's own loader (imageio) has read.  It is host I/O in front of the hot path and is not extended further.
 """
 import struct
 import zlib

@@ -126,7 +126,8 @@ class Plan:
         """target / weight: any strided [B,P,3] views (stride 0 broadcasts); returns
         (loss_terms[4] device tensor, dZ or None, dparams or None, out or None).
         idx (int64 device tensor [B]): Z is a latent TABLE and image b uses row idx[b] (gathered inside the prologue
-        kernel: reni_forward_loss_backward_rows); dZ stays [B,ND,3] in batch order."""
+        kernel: reni_forward_loss_backward_rows); dZ stays [B,ND,3] in batch order.  An index outside the table makes the
+        call's loss and gradients NaN (no out-of-bounds read, no host synchronisation to check it)."""
         _require_cuda(Z, D, params, target, weight, idx)
         Z = _f32c(Z); params = _f32c(params)
         self._check_zp(Z, params)
@@ -159,7 +160,7 @@ class Plan:
                 float(beta), flags, out.data_ptr() if out is not None else None, loss_terms.data_ptr(),
                 dZ.data_ptr() if dZ is not None else None, dparams.data_ptr() if dparams is not None else None, wp, wn, stream)
         if idx is not None:
-            _lib.check(self.lib.reni_forward_loss_backward_rows(self._h, B, P, Z.data_ptr(), idx.data_ptr(), *tail))
+            _lib.check(self.lib.reni_forward_loss_backward_rows(self._h, B, P, Z.data_ptr(), Z.shape[0], idx.data_ptr(), *tail))
         else:
             _lib.check(self.lib.reni_forward_loss_backward(self._h, B, P, Z.data_ptr(), *tail))
         return loss_terms, dZ, dparams, out

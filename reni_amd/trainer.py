@@ -47,20 +47,22 @@ def sync_decoder_grads(model):
             p.grad.mul_(1.0 / w)
 
 
-def gather_latents(model, optimizer=None):
+def gather_latents(model, optimizer=None, rank=None, world=None):
     """Merge the owner-trained latent rows (and, given the optimiser, their Adam moments) into the full table on every
     rank.  Called at the end of ``fit`` and before any checkpoint, so that ``state_dict()`` taken on rank 0 equals the
-    one-process run's (the reference's DDP keeps the full table identical on every rank)."""
-    if rdist.world_size() == 1:
+    one-process run's (the reference's DDP keeps the full table identical on every rank).  ``rank`` / ``world``: the
+    ownership rule ``i % world == rank`` the rows were trained under (default: the process group's)."""
+    w = rdist.world_size() if world is None else world
+    if w == 1:
         return
     with torch.no_grad():
         for _, p in _latent_params(model):
-            rdist.merge_owned_rows_(p.data)
+            rdist.merge_owned_rows_(p.data, rank, world)
             st = optimizer.state.get(p) if optimizer is not None else None
             if st:
                 for k in ("exp_avg", "exp_avg_sq"):
                     if k in st:
-                        rdist.merge_owned_rows_(st[k])
+                        rdist.merge_owned_rows_(st[k], rank, world)
 
 
 def fit(module, max_epochs=None, device=None, batches=None, rank=0, world=1):
@@ -85,6 +87,10 @@ def fit(module, max_epochs=None, device=None, batches=None, rank=0, world=1):
         outs = []
         if batches is not None:
             it = []
+            if world > 1:  # the merge at the end keeps row i from rank i % world only: an explicit batch must respect that
+                for idx in batches:
+                    bad = [i for i in idx if i % world != rank]
+                    assert not bad, f"rank {rank} of {world} was given images {bad} it does not own (i % world == rank)"
             for idx in batches:
                 imgs = torch.stack([module.dataset[i][0] for i in idx])
                 it.append((imgs, torch.tensor(idx)))
@@ -112,5 +118,5 @@ def fit(module, max_epochs=None, device=None, batches=None, rank=0, world=1):
         if sched is not None:
             sched.step()
         module.maybe_double_resolution()
-    gather_latents(module.model, opt)
+    gather_latents(module.model, opt, rank if world > 1 else None, world if world > 1 else None)
     return history

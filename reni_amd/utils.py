@@ -57,7 +57,7 @@ def sRGB(imgs):
     """Linear HDR -> sRGB for viewing (utils.py:30-42).  Device tensors: the HIP epilogue (reni_unnormalise_srgb)."""
     if len(imgs.shape) == 3:
         imgs = imgs.unsqueeze(0)
-    if imgs.is_cuda:
+    if imgs.is_cuda and imgs.shape[1] == 3:  # (the HIP epilogue is written for 3-channel images; anything else: the formula below)
         from . import ops
         return ops.unnormalise_srgb(imgs, None, srgb=True).to(imgs.dtype)
     q = torch.quantile(torch.quantile(torch.quantile(imgs, 0.98, dim=(1)), 0.98, dim=(1)), 0.98, dim=(1))

@@ -219,11 +219,10 @@ def g7():
     g = torch.Generator().manual_seed(70)
     imgs = torch.rand(N, 3, W // 2, W, generator=g) * 2 - 1
     mask_img = np.array(Image.open(os.path.join(REF, "data/Masks/Mask-3.png")))
-    # torchvision is absent: nearest resize restated (exact 4:1 / 8:1 decimation of a 512x256 mask)
-    hs, ws = mask_img.shape[:2]
-    ri = (np.arange(W // 2) * (hs / (W // 2))).astype(np.int64)
-    ci = (np.arange(W) * (ws / W)).astype(np.int64)
-    mask = torch.from_numpy(mask_img[ri][:, ci, :3].astype(np.float32) / 255.0).reshape(1, -1, 3)
+    # utils.py:81-91: ToTensor (HWC uint8 -> CHW float / 255) -> Resize((W/2, W), NEAREST).  torchvision is absent; its 0.11 tensor
+    # path for Resize(NEAREST) is torch.nn.functional.interpolate(img[None], size, mode="nearest")[0], called here directly.
+    chw = torch.from_numpy(mask_img[..., :3].astype(np.float32) / 255.0).permute(2, 0, 1)
+    mask = torch.nn.functional.interpolate(chw[None], size=(W // 2, W), mode="nearest")[0].permute(1, 2, 0).reshape(1, -1, 3)
     D1 = ref_utils.get_directions(W); S1 = ref_utils.get_sineweight(W) * mask
     opt = torch.optim.Adam(m.parameters(), lr=1e-1)
     crit = ref_loss.RENITestLoss(alpha=1e-7, beta=1e-1)

@@ -215,6 +215,31 @@ def test_get_mask(tmp_path, golden):
     assert abs(float(m.mean()) - 0.188) < 0.01  # Mask-3 keeps ~18.8 % of the pixels
 
 
+@pytest.mark.parametrize("W", [64, 100, 128, 256])
+def test_get_mask_is_the_tensor_nearest_resize(tmp_path, golden, W):
+    """utils.get_mask against what torchvision 0.11's tensor path of Resize(NEAREST) calls -- torch.nn.functional.interpolate(
+    mode="nearest") on the ToTensor-equivalent CHW tensor (utils.py:81-91; the G7 golden's mask is generated the same way since
+    round 3): the fixture's Mask-3, random binary 512 x 256 masks (the index rule at a non-integer ratio too), and, where the
+    reference checkout is present, its five mask files."""
+    import os
+    from PIL import Image
+    srcs = {"mask3": golden("g7_latent_opt.npz")["mask_src"]}
+    rng = np.random.default_rng(W)
+    srcs["rand"] = (rng.random((256, 512)) > 0.5).astype(np.uint8) * 255
+    mdir = "/root/reference/data/Masks"
+    if os.path.isdir(mdir):
+        for f in sorted(os.listdir(mdir)):
+            srcs[f] = np.asarray(Image.open(os.path.join(mdir, f)))
+    for name, src in srcs.items():
+        arr = src if src.ndim == 3 else np.stack([src] * 3, -1)
+        path = tmp_path / f"{name}.png"
+        Image.fromarray(arr).save(path)
+        got = utils.get_mask(W, str(path))
+        chw = torch.from_numpy(arr[..., :3].astype(np.float32) / 255.0).permute(2, 0, 1)
+        want = torch.nn.functional.interpolate(chw[None], size=(W // 2, W), mode="nearest")[0].permute(1, 2, 0).reshape(1, -1, 3)
+        assert torch.equal(got, want), name
+
+
 def test_hdr_transforms_match_reference(golden):
     """MinMaxNormalise / UnMinMaxNormlise / UnNormalise / sRGB against the reference's outputs (G12)."""
     from reni_amd.custom_transforms import MinMaxNormalise, UnMinMaxNormlise, UnNormalise, transform_builder

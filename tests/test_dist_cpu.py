@@ -117,3 +117,23 @@ def test_gloo_world2_grad_sync():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_ownership_and_step_counts_of_config_3():
+    """BASELINE config 3's partition (615 images over 8 ranks, 64 images per rank and step): every image has exactly one owner
+    (`i % world`, what DistributedSampler(shuffle=False) gives the reference's un-shuffled loader, run.py:97-110), the owners'
+    shares differ by at most one, and EVERY rank runs the same number of steps per epoch -- so the per-step all-reduce pairs up."""
+    from reni_amd import dist as rdist
+    n, world, B = 615, 8, 64
+    owned = [rdist.owned_indices(n, r, world) for r in range(world)]
+    assert sorted(i for o in owned for i in o) == list(range(n))
+    assert {len(o) for o in owned} <= {76, 77} and all(i % world == r for r, o in enumerate(owned) for i in o)
+    steps = rdist.steps_per_epoch(n, B, world)
+    assert steps == 2  # ceil(77 / 64)
+    for r in range(world):
+        bs = rdist.epoch_batches(n, B, r, world)
+        assert len(bs) == steps and [i for b in bs for i in b] == owned[r]
+        assert len(bs[0]) == 64 and len(bs[1]) in (12, 13)
+    # bench.py's per-GPU batch: 64 <= the smallest share, so every rank can draw a full batch at every N in {1, 2, 4, 8}
+    for w in (1, 2, 4, 8):
+        assert min(len(rdist.owned_indices(n, r, w)) for r in range(w)) >= 64

@@ -168,10 +168,16 @@ def test_cosine_loss_on_the_persistent_kernels(dev, L):
         if need_dw:
             gp = unflatten(spec, dp.cpu())
             for k in gp:
-                # the head bias gradient is three sums of signed per-sample terms that largely cancel: bf16 rounding of the
-                # terms shows at 4-7e-2 on one of the four problems, on the generic kernel as on the persistent one
-                t = tol["grad"] * (3 if gp[k].numel() <= 3 else 1)
-                assert O.rel_l2(gp[k].numpy(), ref["grads"][k].numpy()) <= t, k
+                t = tol["grad"]
+                if gp[k].numel() <= 3:
+                    # The head bias gradient is three sums of signed per-sample terms that largely cancel, so the bf16 error of
+                    # the OUTPUTS shows in it magnified (the kernel sums the terms themselves in fp32).  Its bound is what the
+                    # reference's own arithmetic gives on this problem when its linear layers run in bf16 (autocast), x 1.5.
+                    with torch.autocast("cpu", dtype=torch.bfloat16):
+                        rb = O.fwd_loss_bwd(spec, params, Z, D.expand(B, P, 3), T, Wm.expand(B, P, 3), "test", 1e-3, 1e-1)
+                    t = max(t, 1.5 * O.rel_l2(rb["grads"][k].float().numpy(), ref["grads"][k].numpy()))
+                e = O.rel_l2(gp[k].numpy(), ref["grads"][k].numpy())
+                assert e <= t, (k, e, t)
 
 
 @pytest.mark.parametrize("need_dw", [False, True])

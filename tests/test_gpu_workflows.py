@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import reni_oracle as O
-from tests.util import flat_params, load_golden, make_plan, random_problem, sd_from
+from tests.util import flat_params, load_golden, make_plan, random_problem, sd_from, unflatten
 
 pytestmark = pytest.mark.gpu
 
@@ -207,6 +207,55 @@ def test_c2_full_size_additivity(dev, dtype):
     assert float((out[:, sl].cpu() - ref).abs().max()) <= tol
 
 
+def _oracle_f64(spec, params, Z, D, T, W):
+    """float64 factored oracle (pinned to the reference's autograd by tests/test_oracle_golden.py) on numpy copies."""
+    return O.factored_fwd_bwd(spec, {k: v.numpy() for k, v in params.items()}, Z.numpy(), D.numpy(), T.numpy(), W.numpy())
+
+
+def _assert_training_parity(spec, params, lt, dZ, dp, ref, tol_grad, tol_loss):
+    assert abs(float(lt[0]) - ref["loss_terms"][0]) <= tol_loss * abs(ref["loss_terms"][0])
+    assert O.rel_l2(dZ.cpu().numpy(), ref["dZ"]) <= tol_grad
+    gp = unflatten(spec, dp.cpu())
+    for k in gp:
+        assert O.rel_l2(gp[k].numpy(), ref["grads"][k]) <= tol_grad, (k, O.rel_l2(gp[k].numpy(), ref["grads"][k]))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_c2_training_instance_against_the_oracle_with_many_tiles_per_workgroup(dev, dtype):
+    """The regime bench.py runs the concat training instance in -- many tiles per workgroup, image runs cut inside
+    workgroup ranges, the dW accumulators carried across tiles in AGPRs -- compared DIRECTLY with the float64 oracle
+    (RENI_module.py:105-118: model call + RENITrainLoss; every other oracle comparison of k_reni_train_bf16<128,true>
+    has fewer tiles than workgroups): config-2 architecture, B = 8 images x 32 768 directions = 2 048 tiles, 8 per
+    workgroup, every second workgroup range crossing no image boundary and every 32nd crossing one.  Loss, dZ and
+    every dW / db.  The fp32 generic kernel on the same problem is the cross-check."""
+    spec = O.DecoderSpec(36, "SO2", 128, 5, 3, True, "tanh")
+    B = 8
+    params, Z, D, W, _ = random_problem(spec, B, 0, seed=31, grid_w=256)
+    T = O.synthetic_images(list(range(B)), 128, 256).permute(0, 2, 3, 1).reshape(B, -1, 3)
+    ref = _oracle_f64(spec, params, Z, D, T, W.expand(1, -1, 3))
+    plan = make_plan(spec, dtype)
+    fp = flat_params(spec, params).to(dev)
+    lt, dZ, dp, _ = plan.forward_loss_backward(Z.to(dev), D.to(dev), fp, T.to(dev), W.to(dev))
+    tol = (3e-2, 2e-3) if dtype == "bf16" else (1e-5, 2e-6)
+    _assert_training_parity(spec, params, lt, dZ, dp, ref, *tol)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_c2_training_instance_against_the_oracle_with_700_one_tile_images(dev, dtype):
+    """As above with 700 images of ONE tile each (P = 96 directions): every workgroup's range holds two or three whole
+    images, so every tile ends an image run (per-image dA and loss leave the chip each tile) while the weight-gradient
+    accumulators carry on across them."""
+    spec = O.DecoderSpec(36, "SO2", 128, 5, 3, True, "tanh")
+    B, P = 700, 96
+    params, Z, D, W, T = random_problem(spec, B, P, seed=32)
+    ref = _oracle_f64(spec, params, Z, D, T, W)
+    plan = make_plan(spec, dtype)
+    fp = flat_params(spec, params).to(dev)
+    lt, dZ, dp, _ = plan.forward_loss_backward(Z.to(dev), D.to(dev), fp, T.to(dev), W.to(dev))
+    tol = (3e-2, 2e-3) if dtype == "bf16" else (1e-5, 2e-6)
+    _assert_training_parity(spec, params, lt, dZ, dp, ref, *tol)
+
+
 def test_multires_curriculum_and_exponential_lr(dev):
     """MultiResTrainingCallback semantics (callbacks.py:11-29) and the per-epoch ExponentialLR
     (RENI_module.py:213-214, 243-251) through the fit loop: the grids, the dataset and the kernels' problem size
@@ -336,6 +385,23 @@ def test_reni_forward_is_the_models_forward(dev):
     assert float((out_latent.cpu() - ref).abs().max()) <= 1e-5
     assert torch.equal(out_idx, out_latent)
     assert torch.equal(out_one, out_latent[1:2])
+
+
+def test_rows_entry_poisons_an_out_of_range_index_with_nan(dev):
+    """reni_forward_loss_backward_rows takes the table's row count; an index outside it (a global / local mix-up with
+    sharded tables) reads nothing outside the table and makes the call's loss and gradients NaN -- the reference's Z[idx]
+    (RENI_module.py:97-103) raises a device-side assert; silently training on out-of-bounds memory is the one thing not allowed."""
+    spec = O.DecoderSpec(9, "SO2", 128, 3, 3, True, "tanh")
+    params, Ztab, D, W, T = random_problem(spec, 7, 300, seed=22)
+    for dtype in ("f32", "bf16"):
+        plan = make_plan(spec, dtype)
+        fp = flat_params(spec, params).to(dev)
+        good = plan.forward_loss_backward(Ztab.to(dev), D.to(dev), fp, T[:3].to(dev), W.to(dev), idx=torch.tensor([6, 0, 2], device=dev))
+        assert bool(torch.isfinite(good[0]).all()) and bool(torch.isfinite(good[1]).all()) and bool(torch.isfinite(good[2]).all())
+        for bad_row in (7, -1, 10 ** 9):
+            bad = plan.forward_loss_backward(Ztab.to(dev), D.to(dev), fp, T[:3].to(dev), W.to(dev),
+                                             idx=torch.tensor([6, bad_row, 2], device=dev))
+            assert bool(torch.isnan(bad[0][0])) and bool(torch.isnan(bad[1][1]).all()) and bool(torch.isnan(bad[2]).any())
 
 
 def test_rows_entry_and_fused_adam_equal_the_separate_calls(dev):
