@@ -134,6 +134,20 @@ def test_bench_spawns_its_own_ranks():
     assert line["roofline"]["kernel_launches"] == 2
 
 
+def test_bench_default_line_carries_every_baseline_config_and_the_capi_exchange():
+    """bench.py's default line: the config-2 headline plus `also` sub-records for config 4, config 5 and the FiLM step measured
+    in the same process, each with its own roofline; and `--comm capi` routes the step's exchange through
+    the C ABI's reni_allreduce_grads (here a one-rank communicator: the same call path as N > 1)."""
+    line = _run_bench({}, "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert set(line["also"]) == {"c4", "c5", "film"}
+    for c, flop in (("c4", 348448), ("c5", 177860), ("film", 424480)):
+        r = line["also"][c]
+        assert r["value"] > 0 and r["ms_per_step"] > 0 and r["roofline"]["flop_per_sample"] == flop and r["roofline"]["kernel_avg_ms"] > 0
+    assert line["roofline"]["flop_per_sample"] == 522784 and "also" not in line["also"]["c4"]
+    capi = _run_bench({}, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--comm", "capi")
+    assert "also" not in capi and capi["config"]["exchange_step"].startswith("reni_allreduce_grads") and capi["value"] > 0
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")
 def test_bench_two_ranks_over_rccl():
     """The exchange step on the real transport: backend "nccl" (= RCCL) on two GPUs, self-launched."""
