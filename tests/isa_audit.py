@@ -4,7 +4,7 @@ For every `v_mfma_*` the audit walks every control-flow path that leaves it and 
 until the first instruction that touches the MFMA's destination registers and is not the next MFMA of
 the same accumulate chain.  `s_nop N` counts N + 1, every other instruction 1, a TAKEN branch 0 (the
 strict reading; hipcc's own hazard recogniser counts it as 1 and was seen to misplace its padding behind
-a block-ending MFMA -- see PolF32::drain in reni_amd/csrc/reni_device.inc).  The kernels pad their own chains, so the
+a block-ending MFMA -- see PolF32::drain in reni_amd/csrc/reni_dev_common.inc).  The kernels pad their own chains, so the
 strict count must still reach the XDL write-back latency.
 
 Usage as a script:  python tests/isa_audit.py file.s

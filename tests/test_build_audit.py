@@ -1,7 +1,7 @@
 """CPU-side audit of the emitted gfx950 ISA (hipcc cross-compiles without a GPU).
 
 The persistent bf16 training kernel owns all 256 AGPRs by hand (sixteen literal accumulator tiles,
-reni_amd/csrc/reni_device.inc: mfma_bf16_agpr_tile).  That is only sound if NO compiler-generated
+reni_amd/csrc/reni_dev_common.inc: mfma_bf16_agpr_tile).  That is only sound if NO compiler-generated
 instruction of that kernel touches an AGPR and the kernel does not spill.  Both are checked here on the
 assembly hipcc emits, so an edit that breaks the invariant fails the CPU suite."""
 import os
