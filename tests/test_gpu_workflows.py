@@ -256,6 +256,41 @@ def test_c2_training_instance_against_the_oracle_with_700_one_tile_images(dev, d
     _assert_training_parity(spec, params, lt, dZ, dp, ref, *tol)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_h256_training_in_image_chunks(dev, dtype, monkeypatch):
+    """The shipped experiment.yaml width (5 x 256): the fragment-stream training path keeps 11 x 64 KB per tile, so a call whose
+    stream would exceed the plan's cap runs in chunks of whole images (run_backward_chunked): per-image results in place, loss
+    terms and decoder gradient accumulated.  Forced here at a small size (cap 5 MB -> chunks of 2, 2, 1 images, through the
+    latent-table entry point): equal to the one-pass result up to the order of the sums, and to the oracle; and the workspace
+    the library asks for at the BASELINE batch stays under 4 GB."""
+    spec = O.DecoderSpec(9, "SO2", 256, 2, 3, True, "tanh")
+    params, Ztab, D, W, T = random_problem(spec, 7, 300, seed=41)
+    idx = torch.tensor([6, 1, 3, 0, 4], device=dev)
+    Tb = T[:5].to(dev)
+    fp = flat_params(spec, params).to(dev)
+    res = {}
+    for cap in ("100000", "5"):
+        monkeypatch.setenv("RENI_FRAG_WS_CAP_MB", cap)
+        plan = make_plan(spec, dtype)
+        res[cap] = plan.forward_loss_backward(Ztab.to(dev), D.to(dev), fp, Tb, W.to(dev), loss_kind="test", alpha=1e-3, beta=1e-1,
+                                              idx=idx, want_out=True)
+    one, chunked = res["100000"], res["5"]
+    assert torch.equal(one[3], chunked[3]) and torch.equal(one[1], chunked[1])          # per-image results: bit-equal
+    assert float((one[0] - chunked[0]).abs().max()) <= 1e-5 * float(one[0][0].abs())
+    assert O.rel_l2(chunked[2].cpu().numpy(), one[2].cpu().numpy()) <= 1e-5
+    ref = O.fwd_loss_bwd(spec, params, Ztab[idx.cpu()], D.expand(5, -1, 3), T[:5], W.expand(5, -1, 3), "test", 1e-3, 1e-1)
+    tol = 3e-2 if dtype == "bf16" else 1e-5
+    assert O.rel_l2(chunked[1].cpu().numpy(), ref["dZ"].numpy()) <= tol
+    gp = unflatten(spec, chunked[2].cpu())
+    for k in gp:
+        if gp[k].numel() > 3:
+            assert O.rel_l2(gp[k].numpy(), ref["grads"][k].numpy()) <= tol, k
+    monkeypatch.delenv("RENI_FRAG_WS_CAP_MB")
+    big = make_plan(O.DecoderSpec(49, "SO2", 256, 5, 3, True, "tanh"), dtype)
+    from reni_amd import _lib
+    assert big.lib.reni_workspace_bytes(big._h, 64, 32768, _lib.NEED_DW | _lib.NEED_DZ) < 4 * 2 ** 30
+
+
 def test_multires_curriculum_and_exponential_lr(dev):
     """MultiResTrainingCallback semantics (callbacks.py:11-29) and the per-epoch ExponentialLR
     (RENI_module.py:213-214, 243-251) through the fit loop: the grids, the dataset and the kernels' problem size
