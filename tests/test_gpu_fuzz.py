@@ -43,8 +43,19 @@ def test_fuzz_against_oracle(c):
     S = torch.rand(1, P, 3, generator=gen) + 0.1
     T = torch.rand(B, P, 3, generator=gen) * 2 - 1
     tol = dict(TOL[c["dtype"]])
-    if c["dtype"] == "bf16" and L > 5:
-        tol["grad"] *= (L + 2) / 6.0  # deeper than any shipped configuration: bf16 rounding compounds per layer (600-case run)
+    # Outside the shipped configurations' regime -- more than five hidden layers (bf16 rounding compounds per layer), or a handful of
+    # samples (no averaging over directions behind the bf16 rounding of each) -- the bf16 gradient tolerance is not a constant but
+    # what THE REFERENCE'S OWN ARITHMETIC gives on the same problem with its linear layers in bf16 (autocast), x 1.5, never below the
+    # 3e-2 of SURVEY 8c (the constants 8e-2 and (L + 2) / 6 that stood here asserted less than they seemed to).
+    own_bf16 = c["dtype"] == "bf16" and (L > 5 or B * P < 256) and B * P >= 8
+
+    def bf16_bound(ref, run_ref):
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            rb = run_ref()
+        errs = [O.rel_l2(rb["dZ"].float().numpy(), ref["dZ"].numpy())]
+        errs += [O.rel_l2(rb["grads"][k].float().numpy(), v.numpy()) for k, v in ref["grads"].items() if float(v.abs().max()) > 0]
+        return max(TOL["bf16"]["grad"], 1.5 * max(errs))
+
     if c["dtype"] == "bf16" and B * P < 8:
         # A gradient from fewer than eight samples through up to eight sine layers is ill-conditioned: on the one-sample
         # case of a 600-case run fp32 itself kept 3.5 digits (3e-4) and bf16 none (profiles/tools/gpu_fuzz_one.py).  A bf16 gradient
@@ -52,14 +63,13 @@ def test_fuzz_against_oracle(c):
         # checked through the fp32 kernels instead, at the precision fp32 keeps on them.
         c = dict(c, dtype="f32")
         tol = dict(loss=5e-6, grad=1e-3)
-    elif c["dtype"] == "bf16" and B * P < 256:
-        tol["grad"] = 8e-2  # a handful of samples: no averaging over directions behind the bf16 rounding of each (a 7-layer
-        # FiLM net with one image of 129 directions reached 4.3e-2 on its mapping network's first layer in a 240-case run)
     if c["film"]:
         from reni_amd.film import RENIAutoDecoderFiLM
         spec = O.FilmSpec(nd, c["eq"], H, L + 1, 12, 1, 3, c["act"])
         params = O.film_init_params(spec, gen)
         ref = O.film_fwd_loss_bwd(spec, params, Z, D.expand(B, P, 3), T, S)
+        if own_bf16:
+            tol["grad"] = bf16_bound(ref, lambda: O.film_fwd_loss_bwd(spec, params, Z, D.expand(B, P, 3), T, S))
         m = RENIAutoDecoderFiLM(B, nd, c["eq"], H, L + 1, 12, 1, 3, c["act"], c["frozen"])
         m.load_state_dict({"model." + k: v for k, v in params.items()}, strict=False)
         m.set_compute_dtype(c["dtype"]).to(dev)
@@ -77,6 +87,8 @@ def test_fuzz_against_oracle(c):
         spec = O.DecoderSpec(nd, c["eq"], H, L, 3, True, c["act"])
         params = O.init_params(spec, gen)
         ref = O.fwd_loss_bwd(spec, params, Z, D.expand(B, P, 3), T, S.expand(B, P, 3))
+        if own_bf16:
+            tol["grad"] = bf16_bound(ref, lambda: O.fwd_loss_bwd(spec, params, Z, D.expand(B, P, 3), T, S.expand(B, P, 3)))
         plan = make_plan(spec, c["dtype"])
         fp = flat_params(spec, params).to(dev)
         lt, dZ, dp, out = plan.forward_loss_backward(Z.to(dev), D.to(dev), fp, T.to(dev), S.to(dev), need_dw=not c["frozen"], want_out=True)
