@@ -366,9 +366,10 @@ def main():
         # the other BASELINE configurations (and the reference's default conditioning) measured in the same process, 20 steps each:
         # sub-records beside the headline line, each with its own ms_per_step / roofline
         also = {}
-        for c in ("c4", "c5", "film"):
+        for c in ("c4", "c5", "film", "c2_b100"):
             args.dtype = None
-            r = run_config(c, args, rank, world, dev, steps=20, warmup=3)
+            # (c2_b100: config 2 at the shipped experiment.yaml's batch of 100 images -- one GPU only: 8 ranks own 76-77 images each)
+            r = run_config("c2" if c == "c2_b100" else c, args, rank, world, dev, steps=20, warmup=3, batch=100 if c == "c2_b100" else None)
             also[c] = {"metric": "directional-samples/sec (fwd), 512x1024 equirect, ND=49 latent" if c == "c5" else line["metric"],
                        "value": r["value"], "unit": "samples/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"],
                        "dtype": r["dtype"], "workload": r["config"]["workload"],

@@ -139,7 +139,7 @@ def test_bench_default_line_carries_every_baseline_config_and_the_capi_exchange(
     in the same process, each with its own roofline; and `--comm capi` routes the step's exchange through
     the C ABI's reni_allreduce_grads (here a one-rank communicator: the same call path as N > 1)."""
     line = _run_bench({}, "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
-    assert set(line["also"]) == {"c4", "c5", "film"}
+    assert set(line["also"]) == {"c4", "c5", "film", "c2_b100"} and line["also"]["c2_b100"]["images_per_gpu_per_step"] == 100
     for c, flop in (("c4", 348448), ("c5", 177860), ("film", 424480)):
         r = line["also"][c]
         assert r["value"] > 0 and r["ms_per_step"] > 0 and r["roofline"]["flop_per_sample"] == flop and r["roofline"]["kernel_avg_ms"] > 0
