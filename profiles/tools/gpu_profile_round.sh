@@ -26,8 +26,11 @@ for c in c2 c4 c5 film; do
   python bench.py --config $c $X > $O/bench_$c.json 2>> $O/bench.err; cut -c1-200 $O/bench_$c.json
 done
 for c in c2 c4 c5 film; do
-  rocprofv3 --kernel-trace --stats -d $O/kt_$c -o k -- python3 bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline --no-also > $O/kt_$c.log 2>&1
-  python3 profiles/summarize_rocpd.py $O/kt_$c/k_results.db $O/kernel_stats_$c.md > /dev/null 2>&1 || ls -R $O/kt_$c | head
+  # c2: the DEFAULT command (sub-records first, then the headline's 5 + 20 steps): the summary's last line is the average of the
+  # headline's 20 timed launches
+  X="--config $c --steps 10 --warmup 2 --no-also"; K=""; [ $c = c2 ] && { X="--steps 20 --warmup 5"; K=20; }
+  rocprofv3 --kernel-trace --stats -d $O/kt_$c -o k -- python3 bench.py $X --no-cpu-baseline > $O/kt_$c.log 2>&1
+  python3 profiles/summarize_rocpd.py $O/kt_$c/k_results.db $O/kernel_stats_$c.md $K > /dev/null 2>&1 || ls -R $O/kt_$c | head
   { [ $c = c2 ] || [ $c = film ]; } && python3 profiles/timeline_rocpd.py $O/kt_$c/k_results.db > $O/step_timeline_$c.txt 2>/dev/null
   rm -rf $O/kt_$c
 done
