@@ -40,7 +40,7 @@ struct MainArgs {
   float* dA_part;    // [n_tiles][H][8]: columns dx, dy, dz, r, 1 (hi + lo parts summed), 3 unused
   float* loss_part;  // [n_tiles][4][16]
   char* g1;          // [n_tiles][H/16][256][16 B] bf16 g_1 stream (persistent training path)
-  float* dw1p;       // [2 nwg][H * H + H] k_reni_dw1's weight-gradient partials (layer 1); k_reni_dw1_ring fills the first nwg
+  float* dw1p;       // [2 nwg][H * H + H] k_reni_dw1's weight-gradient partials (layer 1)
   long long* trace;  // optional (tag, s_memtime) pairs from workgroup 0 (RENI_TRACE builds)
   // FiLM conditioning (k_reni_main<..., FILM = true>): hidden layer l in 1..L of image b applies
   // sin(freq . (W_l h + b_l) + phase); film[b][l-1][0][.] = freq, [1][.] = phase
