@@ -285,3 +285,19 @@ def test_envmap_shader_surface():
         es.build_renderer("teapot.obj", 90, 128, 0.5, "cpu")
     r = es.GBufferRenderer(es.GBuffer(torch.randn(16, 3), torch.randn(16, 3), [0.0, 0.0, 2.0], 4), kd=0.3)
     assert abs(r.ks - 0.7) < 1e-12 and r.shininess == 500.0 and r.gbuffer.image_size == (4, 4)
+
+
+def test_pmc_traffic_record_belongs_to_the_committed_kernel_sources():
+    """bench.py's `roofline.traffic` comes from profiles/pmc_traffic.json and is printed only when the record's source hash equals
+    the hash of reni_amd/csrc -- a kernel edit without a new PMC pass (profiles/tools/gpu_profile_round.sh) must not go unnoticed."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    rec = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    sha = bench.kernel_src_sha()
+    for kernel in ("k_reni_train_bf16<128,true>", "k_reni_train_bf16<128,false>", "k_reni_main<f32,H=128,FWD>"):
+        assert rec[kernel]["src_sha256"] == sha, f"{kernel}: PMC record is of another source state"
+        assert bench.pmc_record(kernel).get("hbm_bytes_per_launch"), kernel
