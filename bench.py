@@ -366,7 +366,7 @@ def main():
     also = None
     head = run_config(cfg, args, rank, world, dev, batch=args.batch, defer=True)  # set-up only; measured below
     if cfg == "c2" and not args.no_also:
-        # The other BASELINE configurations (and the reference's default conditioning) measured in the same process, 20 steps each:
+        # The other BASELINE configurations (and the reference's default conditioning) measured in the same process, 20 timed steps behind 10 warm-up steps each:
         # sub-records beside the headline line, each with its own ms_per_step / roofline.  They run FIRST:
         # a GPU that has just been idle takes ~30 ms of load to reach its sustained clocks (the headline's 20-step
         # window behind 5 warm-up steps alone reads 4-5 % lower than every longer run), and these ~0.2 s of real work put the
@@ -378,7 +378,7 @@ def main():
         user_dtype = args.dtype
         for c in (("c4", "c5", "film", "c2_b100") if world == 1 else ("c4", "c5")):
             args.dtype = None
-            r = run_config("c2" if c == "c2_b100" else c, args, rank, world, dev, steps=20, warmup=3, batch=100 if c == "c2_b100" else None)
+            r = run_config("c2" if c == "c2_b100" else c, args, rank, world, dev, steps=20, warmup=10, batch=100 if c == "c2_b100" else None)
             also[c] = {"metric": metric_of(c), "value": r["value"] / (world if c in ("c4", "c5") else 1), "unit": "samples/s",
                        "ms_per_step": r["ms_per_step"], "steps": r["steps"],
                        "dtype": r["dtype"], "workload": r["config"]["workload"],
