@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's headline metric on the fused HIP path.
 
-    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5|film]
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5|film|c2_curric|c2_h256]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Metric  : directional samples / second (one sample = one (image, direction) pair through encoding -> SIREN ->
@@ -16,12 +16,21 @@ Workload: --config c2 (default, the configuration BASELINE.json's metric is quot
           latent forward/backward + Adam on the latent rows.  No collective (every rank: its own 21 maps).
           --config film: config 2's training step with the reference's DEFAULT conditioning (configs/default.py:9: FiLM,
                          5 FiLM layers x 128, mapping network 3 x 128) -- not a BASELINE config, reported beside it.
-          --config c5 (BASELINE config 5): fp32 inference at 512x1024 directions, ND = 49, 4 images per step.
+          --config c5 (BASELINE config 5): fp32 inference at 512x1024 directions, ND = 49, 4 images per step (SO2; the record also
+                         carries the SO3 model of SURVEY 8(d) C5 as `so3`).
+          --config c2_curric: config 2's step in the reference's REAL schedule (configs/experiment.yaml:29-34, callbacks.py:11-29):
+                         B = 100 at 16x32, 32x64 and 64x128, one record per resolution -- a step there is its dependent launches.
+          --config c2_h256: config 2's step at the width the reference's shipped configs use (configs/default.py:13: 5 x 256).
           Synthetic images / random-init weights (seed 42).
 Scaling : weak (per-GPU batch fixed; images and their latent rows sharded round-robin over ranks).
 Launch  : with WORLD_SIZE / RANK in the environment (torchrun) this process is one rank.  Without them and --gpus N > 1
           it spawns N rank processes itself -- BEFORE anything touches the GPU -- and returns the worst exit code.
 
+Headline: `value` / `ms_per_step` / `roofline` are ONE measurement -- W warm-up steps, barrier, exactly K timed steps, barrier --
+          taken FIRST, right behind the set-up, identically with and without the sub-records (`--no-also`).  A GPU that has been idle
+          needs ~30 ms of load to reach its sustained clocks, so with a short warm-up that window reads
+          ~4 % below what a training run sees; the same W + K steps measured again behind the sub-records are reported beside it
+          as `sustained` (a side field, never `value`).
 Rank 0 prints ONE JSON line (contract in the task statement) including `roofline` (dominant kernel, timed live with HIP
 events on its own stream) and, at N = 1, `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded
 sample: B = 1 and B = 4 images, 3 warm-up + 10 timed steps each, reference-shaped and factored -- SURVEY.md 8d).
@@ -52,7 +61,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5", "film"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5", "film", "c2_curric", "c2_h256"])
     ap.add_argument("--batch", type=int, default=None,
                     help="images per GPU per step (c2: 64, <= 615/8 so that 8 ranks can own them; c4: 21; c5: 4)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32"], help="c2 / c4: bf16, c5: f32")
@@ -65,12 +74,16 @@ def parse():
     return ap.parse_args()
 
 
+EXIT_RENDEZVOUS = 75  # a rank that could not join the process group (main() exits with it): the one failure spawn_ranks retries
+
+
 def spawn_ranks(n):
     """python bench.py --gpus N without a launcher: start N rank processes (children of this one, which has not
     touched the GPU and never will) with the environment torchrun would give them; rank 0's stdout is ours.
     The children are polled: the first one to fail takes its siblings down with it (they would otherwise sit in
-    init_process_group / the all-reduce until the process-group timeout), and a failed rendezvous is retried once on
-    a fresh port (the port is picked by bind-and-close, which a concurrent run can win)."""
+    init_process_group / the all-reduce until the process-group timeout).  ONLY a failed rendezvous (EXIT_RENDEZVOUS: the port,
+    picked by bind-and-close, was taken by a concurrent run) is retried, once, on a fresh port -- any other failure is
+    deterministic and running it twice would at best print a second line."""
     def launch():
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
@@ -84,15 +97,15 @@ def spawn_ranks(n):
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
         return procs
 
+    rc = 0
     for attempt in range(2):
         procs = launch()
-        t0 = time.time()
         rc = 0
         while True:
             codes = [p.poll() for p in procs]
             bad = [c for c in codes if c not in (None, 0)]
             if bad:
-                rc = bad[0]
+                rc = EXIT_RENDEZVOUS if EXIT_RENDEZVOUS in bad else bad[0]
                 for p in procs:
                     if p.poll() is None:
                         p.terminate()
@@ -101,13 +114,13 @@ def spawn_ranks(n):
                         p.wait(timeout=10)
                     except subprocess.TimeoutExpired:
                         p.kill()
+                        p.wait()
                 break
             if all(c == 0 for c in codes):
                 return 0
             time.sleep(0.2)
-        if attempt == 0 and time.time() - t0 < 60:  # died at start-up (import, rendezvous): one retry on another port
-            continue
-        return rc
+        if not (attempt == 0 and rc == EXIT_RENDEZVOUS):
+            return rc
     return rc
 
 
@@ -184,13 +197,44 @@ def issue_ceiling(valu_per_mfma, trans_per_mfma):
     return 33.6 / max(33.6, issue)
 
 
-def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None, defer=False):
+def flop_train(nd, H, L):
+    """SURVEY.md 8(d)'s per-sample work of one fwd+bwd training step, factored form (2 FLOP per MAC): forward
+    F = (ND+2) H + 2 ND + L H^2 + 3 H, backward Bt = 2 (L H^2 + 3 H) + (ND+2) H + ND H + 2 ND.  (ND=36, H=128, L=5: 522 784.)"""
+    F = (nd + 2) * H + 2 * nd + L * H * H + 3 * H
+    Bt = 2 * (L * H * H + 3 * H) + (nd + 2) * H + nd * H + 2 * nd
+    return 2 * (F + Bt)
+
+
+_IMG_CACHE = {}
+
+
+def _resident_images(n_images, h, w, owned, dev):
+    """This rank's shard of the synthetic set, resident in HBM (shared by the configurations of one process that use the same set)."""
+    import torch
+    from reni_amd.data import SyntheticEnvMapDataset
+    key = (n_images, h, w, len(owned), owned[0] if owned else -1, str(dev))
+    if key not in _IMG_CACHE:
+        ds = SyntheticEnvMapDataset(n_images, h, w)
+        _IMG_CACHE[key] = torch.stack([ds.make(i) for i in owned]).to(dev)      # [n_local,3,H,W]
+    return _IMG_CACHE[key]
+
+
+def mask3(sidelen):
+    """The reference's data/Masks/Mask-3.png (examples.ipynb cell 4) at this resolution: its 256 x 512 source travels as plain
+    data in tests/golden/g7_latent_opt.npz (`mask_src`); resized exactly as utils.get_mask does (utils.py:81-91)."""
+    import numpy as np
+    from reni_amd.utils import mask_from_array
+    src = np.load(os.path.join(ROOT, "tests", "golden", "g7_latent_opt.npz"))["mask_src"]
+    return mask_from_array(sidelen, src)
+
+
+def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None, defer=False, res=None, hidden=128, eq="SO2"):
     """One bench configuration in this process: build the model / engine, warm up, time `steps` steps between barriers.
-    Returns the record (value, ms_per_step, roofline ...) on every rank; timing is the MAX over ranks."""
+    Returns the record (value, ms_per_step, roofline ...) on every rank; timing is the MAX over ranks.
+    res = (height, width) of the c2 step's images (the multi-resolution curriculum), hidden = the SIREN's width."""
     import torch
     from reni_amd import dist as rdist
     from reni_amd import ops
-    from reni_amd.data import SyntheticEnvMapDataset
     from reni_amd.engine import TrainEngine
     from reni_amd.models import RENIAutoDecoder
     from reni_amd.utils import get_directions, get_sineweight
@@ -201,9 +245,9 @@ def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None,
     dtype = args.dtype or ("f32" if cfg == "c5" else "bf16")
     torch.manual_seed(42)
     if cfg == "c2":
-        N_IMAGES, H_IMG, W_IMG, ND, B = 615, 128, 256, 36, batch or 64
+        N_IMAGES, (H_IMG, W_IMG), ND, B = 615, res or (128, 256), 36, batch or 64
         owned = rdist.owned_indices(N_IMAGES, rank, world)
-        model = RENIAutoDecoder(N_IMAGES, ND, "SO2", 128, 5, 3, True, "tanh", 30.0, 30.0, False)
+        model = RENIAutoDecoder(N_IMAGES, ND, "SO2", hidden, 5, 3, True, "tanh", 30.0, 30.0, False)
     elif cfg == "film":
         from reni_amd.film import RENIAutoDecoderFiLM
         N_IMAGES, H_IMG, W_IMG, ND, B = 615, 128, 256, 36, batch or 64
@@ -218,7 +262,7 @@ def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None,
     else:
         N_IMAGES, H_IMG, W_IMG, ND, B = 4, 512, 1024, 49, batch or 4
         owned = list(range(N_IMAGES))
-        model = RENIAutoDecoder(N_IMAGES, ND, "SO2", 128, 5, 3, True, "tanh", 30.0, 30.0, True)
+        model = RENIAutoDecoder(N_IMAGES, ND, eq, 128, 5, 3, True, "tanh", 30.0, 30.0, True)
         with torch.no_grad():
             model.Z.normal_()
     model.set_compute_dtype(dtype)
@@ -233,11 +277,10 @@ def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None,
     sineweight = get_sineweight(W_IMG).to(dev)
     P = directions.shape[1]
     idx_all = torch.arange(n_local, device=dev)  # (the loader's indices: resident like the images)
+    eng = None
 
     if cfg in ("c2", "c4", "film"):
-        # this rank's shard of the synthetic set, resident in HBM before the timed region
-        ds = SyntheticEnvMapDataset(N_IMAGES, H_IMG, W_IMG)
-        imgs = torch.stack([ds.make(i) for i in owned]).to(dev)      # [n_local,3,H,W], ~0.39 MB per image
+        imgs = _resident_images(N_IMAGES, H_IMG, W_IMG, owned, dev)  # resident in HBM before the timed region; ~0.39 MB per image
         comm = None
         if args.comm == "capi" and cfg in ("c2", "film"):  # the exchange step through the C ABI's reni_allreduce_grads
             comm = rdist.RcclComm(rank, world)
@@ -245,10 +288,9 @@ def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None,
             eng = TrainEngine(model, lr=1e-5, comm=comm)
             weight = sineweight
         else:
-            # inpainting mask of the notebook's kind (examples.ipynb cell 4, Mask-3: 18.8 % of the pixels kept): a
-            # synthetic binary column mask with the same kept fraction, multiplied into the sine weight (RENI_module.py:92-94)
-            keep = (torch.arange(W_IMG, device=dev) < int(0.188 * W_IMG)).float().view(1, 1, W_IMG, 1).expand(1, H_IMG, W_IMG, 3)
-            weight = sineweight * keep.reshape(1, P, 3)
+            # the notebook's inpainting mask (examples.ipynb cell 4: data/Masks/Mask-3.png, rows 20-92 x columns 81-164 of 128 x 256
+            # kept = 18.8 % of the pixels), multiplied into the sine weight (RENI_module.py:92-94)
+            weight = sineweight * mask3(W_IMG).to(dev)
             eng = TrainEngine(model, lr=1e-1, loss_kind="test", alpha=1e-7, beta=1e-4)
 
         def step(s):
@@ -266,32 +308,44 @@ def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None,
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def measure():
-        return _measure(cfg, args, world, dev, dtype, step, barrier, steps, warmup, B, P)
+    shape = {"cfg": cfg, "B": B, "P": P, "ND": ND, "hidden": hidden, "res": (H_IMG, W_IMG), "eq": eq}
+    try:
+        paths = model._plan().path_info(B, P, need_dw=cfg in ("c2", "film"))
+    except Exception as e:  # noqa: BLE001  (diagnostics only)
+        paths = {"error": str(e)[:100]}
 
-    # defer: the caller runs other configurations between this set-up (model, resident images, grids) and the measurement
+    def measure():
+        return _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, paths)
+
+    # defer: the caller decides when the measurement runs (the headline: first; again behind the sub-records as `sustained`)
     return measure if defer else measure()
 
 
-def _measure(cfg, args, world, dev, dtype, step, barrier, steps, warmup, B, P):
+def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, paths):
     """W untimed warm-up steps, barrier + synchronize, EXACTLY K timed steps, barrier + synchronize (the driver's contract)."""
     import torch
     from reni_amd import ops
+    cfg, B, P = shape["cfg"], shape["B"], shape["P"]
     for s in range(warmup):
         step(s)
     barrier()
     ops.profile_enable(True)
     ops.profile_read(reset=True, kind=ops.PROF_ALL)
+    ops.launch_count(reset=True)
+    if eng is not None:
+        eng.time_comm(True)
     t0 = time.perf_counter()
     last = None
     for s in range(steps):
         last = step(warmup + s)
     barrier()
     dt = time.perf_counter() - t0
+    launches = ops.launch_count(reset=True)
     kind = ops.PROF_FWD if cfg == "c5" else ops.PROF_FWD_BWD
     kern_ms, kern_n = ops.profile_read(reset=False, kind=kind)
     stats_ms, stats_n = ops.profile_read(reset=True, kind=ops.PROF_STATS)
     ops.profile_enable(False)
+    comm_us = eng.time_comm(False) if eng is not None else None
     check = float(last[0]) if cfg != "c5" else float(last.abs().max())
     assert check == check and abs(check) < 1e6, f"non-finite result {check}"
 
@@ -302,11 +356,13 @@ def _measure(cfg, args, world, dev, dtype, step, barrier, steps, warmup, B, P):
     value = world * B * P * steps / dt
 
     kavg_ms = kern_ms / max(kern_n, 1)
+    H = shape["hidden"]
     if cfg == "c2":
-        flop = FLOP_TRAIN
-        kernel = "k_reni_train_bf16<128,true>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD>"
-        workload = ("BASELINE config 2: 615-image set, 128x256 equirect, ND=36, 5x128 SIREN, SO2, tanh, AutoDecoder, "
-                    "RENITrainLoss; full training step (fwd+loss+bwd, grad all-reduce, Adam)")
+        flop = flop_train(shape["ND"], H, 5)
+        assert H != 128 or flop == FLOP_TRAIN
+        kernel = (f"k_reni_train_bf16<128,true>" if (dtype == "bf16" and H == 128) else f"k_reni_main<{dtype},H={H},FWD_BWD>")
+        workload = (f"BASELINE config 2: 615-image set, {shape['res'][0]}x{shape['res'][1]} equirect, ND=36, 5x{H} SIREN, SO2, tanh, "
+                    "AutoDecoder, RENITrainLoss; full training step (fwd+loss+bwd, grad all-reduce, Adam)")
     elif cfg == "film":
         flop = FLOP_FILM
         kernel = "k_reni_train_bf16<128,true,false,true>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD,FILM>"
@@ -317,13 +373,15 @@ def _measure(cfg, args, world, dev, dtype, step, barrier, steps, warmup, B, P):
         flop = FLOP_FROZEN
         kernel = "k_reni_train_bf16<128,false>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD>"
         workload = ("BASELINE config 4: test-time latent optimisation, 21 held-out maps, 128x256 equirect, ND=36, 5x128 SIREN, "
-                    "frozen decoder, masked (18.8 % kept) RENITestLoss(1e-7,1e-4) with the cosine term, per-image latent "
-                    "Adam lr 0.1; full step (statistics pass + latent fwd/bwd + Adam)")
+                    "frozen decoder, the reference's Mask-3 (18.8 % kept), RENITestLoss(1e-7,1e-4) with the cosine term, per-image "
+                    "latent Adam lr 0.1; full step (statistics pass + latent fwd/bwd + Adam)")
     else:
         flop = FLOP_FWD_ND49
         kernel = "k_reni_main<f32,H=128,FWD>" if dtype == "f32" else "k_reni_train_bf16<128,false,true>"
-        workload = "BASELINE config 5: inference, 512x1024 directions, ND=49, 5x128 SIREN, SO2, 4 images per step"
-    achieved = B * P * flop / (kavg_ms * 1e-3) / 1e12
+        workload = f"BASELINE config 5: inference, 512x1024 directions, ND=49, 5x128 SIREN, {shape['eq']}, 4 images per step"
+    # achieved = the algorithmic FLOPs of the timed steps / the dominant kernel's total run time in them (HIP events on its stream):
+    # per launch this is flop x samples per launch / average launch duration, also when a step is several launches (H = 256: chunks)
+    achieved = B * P * steps * flop / (max(kern_ms, 1e-9) * 1e-3) / 1e12
     pmc = pmc_record(kernel)
     roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
             "frac": achieved / PEAK_TFLOPS[dtype], "traffic": pmc.get("hbm_bytes_per_launch"), "kernel": kernel,
@@ -337,12 +395,49 @@ def _measure(cfg, args, world, dev, dtype, step, barrier, steps, warmup, B, P):
     if stats_n:
         roof["stats_pass_avg_ms"] = stats_ms / stats_n
     rec = {"value": value, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": dtype,
+           "launches_per_step": launches / steps,
            "config": {"workload": workload, "images_per_gpu_per_step": B, "global_batch_images": world * B,
-                      "directions_per_image": P, "parallelism": f"dp{world}", "result_check": check},
+                      "directions_per_image": P, "parallelism": f"dp{world}", "result_check": check, "paths": paths},
            "roofline": roof}
+    if world > 1 and cfg in ("c2", "film"):
+        rec["exchange"] = {"kind": "reni_allreduce_grads (C ABI, librccl)" if args.comm == "capi" else
+                           f"torch.distributed all_reduce ({torch.distributed.get_backend()})",
+                           "avg_us_on_compute_stream": comm_us}
     if args.comm == "capi":
         rec["config"]["exchange_step"] = "reni_allreduce_grads (C ABI, librccl)"
     return rec
+
+
+METRIC_FWD = "directional-samples/sec (fwd), 512x1024 equirect, ND=49 latent"
+METRIC_TRAIN = "directional-samples/sec (fwd+bwd), 128x256 equirect, ND=36 latent"
+CURRIC = ((16, 32), (32, 64), (64, 128))   # configs/experiment.yaml:31-33: INITAL_RESOLUTION doubled at CURRICULUM's epochs
+
+
+def sub_record(name, args, rank, world, dev):
+    """One sub-record of the default line (20 timed steps behind 10 warm-up steps, same process)."""
+    kw = dict(steps=20, warmup=10)
+    if name == "c2_b100":     # config 2 at the shipped experiment.yaml's batch of 100 images
+        r = run_config("c2", args, rank, world, dev, batch=100, **kw)
+    elif name.startswith("c2_curric_"):   # the reference's real schedule: B = 100 at 16x32 / 32x64 / 64x128
+        h, w = (int(x) for x in name[len("c2_curric_"):].split("x"))
+        r = run_config("c2", args, rank, world, dev, batch=100, res=(h, w), **kw)
+    elif name == "c2_h256":   # the width of the reference's shipped configs (configs/default.py:13)
+        r = run_config("c2", args, rank, world, dev, hidden=256, **kw)
+    else:
+        r = run_config(name, args, rank, world, dev, **kw)
+    out = {"metric": METRIC_FWD if name == "c5" else METRIC_TRAIN.replace("128x256", "%dx%d" % tuple(int(x) for x in name[10:].split("x")))
+           if name.startswith("c2_curric_") else METRIC_TRAIN,
+           "value": r["value"] / (world if name in ("c4", "c5") else 1), "unit": "samples/s",
+           "ms_per_step": r["ms_per_step"], "steps": r["steps"], "launches_per_step": r["launches_per_step"],
+           "dtype": r["dtype"], "workload": r["config"]["workload"],
+           "images_per_gpu_per_step": r["config"]["images_per_gpu_per_step"], "paths": r["config"]["paths"], "roofline": r["roofline"]}
+    if name == "c5":  # SURVEY 8(d) C5 names both invariances: the SO3 model through the same kernel
+        r3 = run_config("c5", args, rank, world, dev, eq="SO3", **kw)
+        out["so3"] = {"value": r3["value"] / world, "ms_per_step": r3["ms_per_step"], "frac": r3["roofline"]["frac"],
+                      "kernel_avg_ms": r3["roofline"]["kernel_avg_ms"]}
+    if world > 1:
+        out["note"] = "per GPU (independent replicas)"
+    return out
 
 
 def main():
@@ -352,7 +447,11 @@ def main():
 
     import torch
     from reni_amd import dist as rdist
-    rank, world, local = rdist.init_from_env()
+    try:
+        rank, world, local = rdist.init_from_env()
+    except Exception as e:  # noqa: BLE001  (a failed rendezvous is the one failure spawn_ranks retries: say so with a code of its own)
+        print(f"bench.py: rendezvous failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        sys.exit(EXIT_RENDEZVOUS)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     dev = torch.device("cuda", local)
@@ -361,59 +460,53 @@ def main():
         torch.distributed.all_reduce(torch.zeros(1, device=dev))
 
     cfg = args.config
-    metric_of = lambda c: ("directional-samples/sec (fwd), 512x1024 equirect, ND=49 latent" if c == "c5"
-                           else "directional-samples/sec (fwd+bwd), 128x256 equirect, ND=36 latent")
-    also = None
-    head = run_config(cfg, args, rank, world, dev, batch=args.batch, defer=True)  # set-up only; measured below
-    from_idle = None
+    also, sustained = None, None
+    if cfg == "c2_curric":   # the line's headline = the curriculum's final resolution; all three in `also`
+        also = {f"c2_curric_{h}x{w}": sub_record(f"c2_curric_{h}x{w}", args, rank, world, dev) for h, w in CURRIC}
+        head = run_config("c2", args, rank, world, dev, batch=args.batch or 100, res=CURRIC[-1], defer=True)
+    elif cfg == "c2_h256":
+        head = run_config("c2", args, rank, world, dev, batch=args.batch, hidden=256, defer=True)
+    else:
+        head = run_config(cfg, args, rank, world, dev, batch=args.batch, defer=True)  # set-up only
+    # THE headline: W warm-up + K timed steps, first, identically with and without the sub-records
+    rec = head()
     if cfg == "c2" and not args.no_also:
-        # the same W + K steps measured FIRST as well, from the idle GPU's clocks: reported beside the headline (`from_idle`) so that
-        # the line shows both clock states; `value` is the measurement behind the sub-records
-        r0 = head()
-        from_idle = {"value": r0["value"], "ms_per_step": r0["ms_per_step"], "kernel_avg_ms": r0["roofline"]["kernel_avg_ms"],
-                     "frac": r0["roofline"]["frac"], "steps": r0["steps"], "warmup": r0["warmup"]}
-    if cfg == "c2" and not args.no_also:
-        # The other BASELINE configurations (and the reference's default conditioning) measured in the same process, 20 timed steps behind 10 warm-up steps each:
-        # sub-records beside the headline line, each with its own ms_per_step / roofline.  They run FIRST:
-        # a GPU that has just been idle takes ~30 ms of load to reach its sustained clocks (the headline's 20-step
-        # window behind 5 warm-up steps alone reads 4-5 % lower than every longer run), and these ~0.2 s of real work put the
-        # headline's warm-up + timed steps at the clocks a training run sees (its model, images and grids are set up BEFORE the
-        # sub-records -- `head` above -- so that nothing but the W + K steps follows them).  N > 1: only the two configurations whose ranks are
-        # independent (c4, c5: rank 0's own replica), so that every N is measured in the same clock state.
-        # (c2_b100: config 2 at the shipped experiment.yaml's batch of 100 images -- one GPU only: 8 ranks own 76-77 images each)
+        # The other BASELINE configurations, the reference's default conditioning, its shipped batch / schedule / width, measured in the
+        # same process behind the headline: sub-records, each with its own ms_per_step / launches / roofline.  N > 1: only the two
+        # configurations whose ranks are independent (c4, c5: rank 0's own replica).
         also = {}
         user_dtype = args.dtype
-        for c in (("c4", "c5", "film", "c2_b100") if world == 1 else ("c4", "c5")):
+        names = (("c4", "c5", "film", "c2_b100") + tuple(f"c2_curric_{h}x{w}" for h, w in CURRIC) + ("c2_h256",)) if world == 1 else ("c4", "c5")
+        for c in names:
             args.dtype = None
             try:
-                r = run_config("c2" if c == "c2_b100" else c, args, rank, world, dev, steps=20, warmup=10, batch=100 if c == "c2_b100" else None)
+                also[c] = sub_record(c, args, rank, world, dev)
             except Exception as e:  # a sub-record must not cost the headline its line (one process only: with ranks, fail together)
                 if world > 1:
                     raise
                 also[c] = {"error": f"{type(e).__name__}: {e}"[:300]}
-                continue
-            also[c] = {"metric": metric_of(c), "value": r["value"] / (world if c in ("c4", "c5") else 1), "unit": "samples/s",
-                       "ms_per_step": r["ms_per_step"], "steps": r["steps"],
-                       "dtype": r["dtype"], "workload": r["config"]["workload"],
-                       "images_per_gpu_per_step": r["config"]["images_per_gpu_per_step"], "roofline": r["roofline"]}
-            if world > 1:
-                also[c]["note"] = "per GPU (independent replicas)"
         args.dtype = user_dtype
-    rec = head()
+        # the headline's W + K steps once more, now behind ~0.3 s of load: the clocks a training run sees (side field)
+        r1 = head()
+        sustained = {"value": r1["value"], "ms_per_step": r1["ms_per_step"], "kernel_avg_ms": r1["roofline"]["kernel_avg_ms"],
+                     "frac": r1["roofline"]["frac"], "steps": r1["steps"], "warmup": r1["warmup"],
+                     "note": "the same W + K steps measured again behind the sub-records (GPU at sustained clocks); not `value`"}
     line = {
-        "metric": metric_of(cfg),
+        "metric": METRIC_FWD if cfg == "c5" else METRIC_TRAIN.replace("128x256", "64x128") if cfg == "c2_curric" else METRIC_TRAIN,
         "value": rec["value"], "unit": "samples/s", "n_gpus": world, "steps": rec["steps"], "warmup": rec["warmup"],
         "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic",
         "n_ranks_seen": torch.distributed.get_world_size() if world > 1 else 1,
         "dist_backend": torch.distributed.get_backend() if world > 1 else None,
+        "launches_per_step": rec["launches_per_step"],
         "config": rec["config"], "roofline": rec["roofline"],
     }
+    if "exchange" in rec:
+        line["exchange"] = rec["exchange"]
     if also is not None:
         line["also"] = also
-        line["order"] = ("the headline's W + K steps are measured twice: first from an idle GPU (`from_idle`), then behind the sub-records "
-                         "at sustained clocks (`value`, `ms_per_step`, `roofline`)")
-        line["from_idle"] = from_idle
+    if sustained is not None:
+        line["sustained"] = sustained
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_steps)

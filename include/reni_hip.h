@@ -306,6 +306,27 @@ int reni_allreduce_grads(void* comm, float* flat, size_t n, float scale, void* s
 /* Launch geometry chosen for (B,P): workgroups, threads, dynamic LDS bytes (diagnostics). */
 int reni_launch_info(const reni_plan* plan, int64_t B, int64_t P, int32_t* info4);
 
+/* Which kernels a backward call of this shape will take (diagnostics; no reference counterpart -- the reference has one path).
+ * info8 = { persistent kernels (k_reni_train_bf16) 0/1, dW_1 kernel 0 none / 1 k_reni_dw1_ring / 2 k_reni_dw1,
+ *           side stream 0/1, images per chunk of the H = 256 training path (= B: one pass), operand stream 0/1,
+ *           fragment stream 0 / 1 bf16 / 2 fp32, environment overrides in force (bit 0 RENI_NO_PERSIST, 1 RENI_NO_SIDE_STREAM,
+ *           2 RENI_FRAG_WS_CAP_MB, 3 RENI_DW1_OLD; 0 in a clean environment), workgroups }.
+ * The selectors are read from the environment ONCE, at reni_plan_create; every alternative is a tested, correct path, and
+ * bench.py prints this record so that a stray variable cannot silently change what is measured. */
+int reni_path_info(const reni_plan* plan, int64_t B, int64_t P, uint32_t flags, int32_t* info8);
+
+/* Data-parallel overlap hook (reference: DDP overlaps its bucketed all-reduce with the tail of backward, run.py:97).  While an
+ * event is set (thread-local; NULL clears it), every reni_forward_loss_backward[_rows] call with RENI_NEED_DW records it on the
+ * call's stream at the point where dparams[n_first + H*H + H ...) -- layers >= 2 and the head, 28 % of the gradient at config 2 -- is
+ * final: on the persistent path that is before k_reni_dw1 runs (~0.13 ms before the call's work ends), on every other path at
+ * the end of the call.  The caller makes its communication stream wait for the event and all-reduces that slice there, the
+ * rest behind the call as before.  `hip_event` is a hipEvent_t created by the caller on the buffers' device. */
+int reni_set_grad_ready_event(void* hip_event);
+
+/* Kernel launches the library has issued in this process (all entry points, all streams); reset != 0 returns the count and
+ * sets it to zero.  bench.py reports launches per step: at small problems a step costs its dependent launches. */
+int64_t reni_launch_count(int32_t reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,7 @@ COND_CONCAT, COND_FILM = 0, 1
 EXPORTS = (
     "reni_last_error", "reni_plan_create", "reni_plan_destroy", "reni_param_count", "reni_in_features",
     "reni_workspace_bytes", "reni_forward", "reni_forward_loss_backward", "reni_backward",
-    "reni_forward_loss_backward_rows", "reni_adam_step", "reni_adam_rows_step", "reni_adam_step2", "reni_selftest_layouts", "reni_launch_info", "reni_profile_enable", "reni_profile_read", "reni_profile_read_kind", "reni_probe_tr",
+    "reni_forward_loss_backward_rows", "reni_adam_step", "reni_adam_rows_step", "reni_adam_step2", "reni_selftest_layouts", "reni_launch_info", "reni_path_info", "reni_launch_count", "reni_set_grad_ready_event", "reni_profile_enable", "reni_profile_read", "reni_profile_read_kind", "reni_probe_tr",
     "reni_film_forward", "reni_film_forward_loss_backward", "reni_film_backward",
     "reni_film_map_param_count", "reni_film_model_forward", "reni_film_model_forward_loss_backward",
     "reni_film_model_backward",
@@ -125,6 +125,12 @@ def load():
     lib.reni_selftest_layouts.restype = c_int32
     lib.reni_launch_info.argtypes = [c_void_p, c_int64, c_int64, POINTER(c_int32)]
     lib.reni_launch_info.restype = c_int32
+    lib.reni_path_info.argtypes = [c_void_p, c_int64, c_int64, c_uint32, POINTER(c_int32)]
+    lib.reni_path_info.restype = c_int32
+    lib.reni_set_grad_ready_event.argtypes = [c_void_p]
+    lib.reni_set_grad_ready_event.restype = c_int32
+    lib.reni_launch_count.argtypes = [c_int32]
+    lib.reni_launch_count.restype = c_int64
     lib.reni_profile_enable.argtypes = [c_int32]
     lib.reni_profile_enable.restype = c_int32
     lib.reni_profile_read.argtypes = [POINTER(ctypes.c_double), POINTER(c_int64), c_int32]

@@ -11,16 +11,32 @@ from __future__ import annotations
 
 import torch
 
+import os
+
+from . import _lib, _roctx
 from . import dist as rdist
 from . import ops
 
+if os.environ.get("RENI_ROCTX"):
+    _roctx.enabled = True
+
 
 class TrainEngine:
-    def __init__(self, model, lr: float, loss_kind: str = "mse", alpha: float = 0.0, beta: float = 0.0, comm=None):
+    def __init__(self, model, lr: float, loss_kind: str = "mse", alpha: float = 0.0, beta: float = 0.0, comm=None,
+                 overlap_comm: bool = False):
         """comm: an optional ``dist.RcclComm``; the decoder-gradient all-reduce then goes through the library's own
         ``reni_allreduce_grads`` on the compute stream instead of torch.distributed's nccl backend (the same RCCL ring
-        either way)."""
+        either way).
+        overlap_comm: start the all-reduce of layers >= 2 + head (28 % of the gradient at config 2) on a communication stream as
+        soon as their partial reduction has run -- i.e. beside k_reni_dw1 and the latent tails, ~0.13 ms before the fused call's
+        work ends (``reni_set_grad_ready_event``) -- and all-reduce the rest (first layer, layer 1) behind the call as before.
+        Same sums, element for element (tests/test_gpu_dist.py); what it hides on xGMI is unmeasured (no multi-GPU box so far),
+        so it is off by default."""
         self.comm = comm
+        self.overlap_comm = overlap_comm
+        self._comm_stream = None
+        self._ev_rest = self._ev_comm_done = None
+        self._comm_ev = None        # [(start, end)] torch events around the exchange step while time_comm is on
         self.model = model
         self.plan = model._plan()
         # FiLM-conditioned models (RENI.py:522-858): the optimised buffer is [net | final_layer | mapping_network]
@@ -37,10 +53,39 @@ class TrainEngine:
         self.v_lat = torch.zeros_like(self.latent.data)
         self.t = 0
         self.world = rdist.world_size()
+        if self.overlap_comm and not self.film and self.train_decoder:
+            dev = self.flat.device
+            self._comm_stream = torch.cuda.Stream(dev)
+            self._ev_rest, self._ev_comm_done = torch.cuda.Event(), torch.cuda.Event()
+            with torch.cuda.device(dev):
+                self._ev_rest.record()  # (materialises the hipEvent_t behind the handle)
+            H = self.plan.hidden_features
+            self._n_head = self.plan.n_first + (H * H + H if self.plan.hidden_layers >= 1 else 0)  # [0, n_head): final only at the end
+        else:
+            self.overlap_comm = False
+
+    def time_comm(self, on: bool):
+        """Bracket every exchange step with events on the compute stream (what the step actually waits for).  time_comm(False) returns
+        the average in microseconds (None: no exchange was timed) and stops timing."""
+        if on:
+            self._comm_ev = []
+            return None
+        evs, self._comm_ev = self._comm_ev, None
+        if not evs:
+            return None
+        torch.cuda.synchronize(self.flat.device)
+        return 1e3 * sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+
+    def _allreduce(self, buf):
+        if self.comm is not None:
+            self.comm.allreduce_(buf, 1.0)
+        else:
+            torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM)
 
     def step(self, idx: torch.Tensor, target: torch.Tensor, weight: torch.Tensor, directions: torch.Tensor):
         """idx: rows of this rank's latent table in the batch; target/weight: strided [B,P,3] views.
         Returns the device tensor (loss, mse, prior, cosine) of this rank's batch."""
+        _roctx.push("reni.step.fwd_bwd")
         if self.film:  # mapping network + fused core + glue backward in one library call (reni_film_model_*)
             n = self.plan.n_params
             terms, dZ, dparams, _, _ = self.plan.film_model_forward_loss_backward(
@@ -49,28 +94,54 @@ class TrainEngine:
             if dparams is not None:
                 dparams = dparams._base  # [d params | d map_params]: one buffer, laid out like self.flat
         else:
-            # (the batch's latent rows are gathered inside the prologue kernel: no separate Z[idx] gather)
-            terms, dZ, dparams, _ = self.plan.forward_loss_backward(
-                self.latent.data, directions, self.flat, target, weight, loss_kind=self.loss_kind, alpha=self.alpha,
-                beta=self.beta, need_dw=self.train_decoder, need_dz=True, idx=idx)
+            exchange = self.train_decoder and (self.world > 1 or self.comm is not None)
+            hook = self.overlap_comm and exchange
+            if hook:
+                _lib.check(_lib.load().reni_set_grad_ready_event(self._ev_rest.cuda_event))
+            try:
+                # (the batch's latent rows are gathered inside the prologue kernel: no separate Z[idx] gather)
+                terms, dZ, dparams, _ = self.plan.forward_loss_backward(
+                    self.latent.data, directions, self.flat, target, weight, loss_kind=self.loss_kind, alpha=self.alpha,
+                    beta=self.beta, need_dw=self.train_decoder, need_dz=True, idx=idx)
+            finally:
+                if hook:
+                    _lib.check(_lib.load().reni_set_grad_ready_event(None))
+        _roctx.pop()
         self.t += 1
         inv_w = 1.0 / self.world
         # ONE exchange step: the in-place sum of the flat decoder gradient over the ranks (run.py:97's DDP all-reduce; the 1 / world
         # of its mean rides on Adam's grad_scale).  Either the library's own reni_allreduce_grads on this stream (comm=) or
         # torch.distributed's nccl backend, which orders itself against this stream on the device -- no host wait either way.
         # Latent rows need no communication (dist.py).  FIT_LATENT (frozen decoder): no collective at all.
-        if self.train_decoder and self.world > 1:
-            if self.comm is not None:
-                self.comm.allreduce_(dparams, 1.0)
+        if self.train_decoder and (self.world > 1 or self.comm is not None):  # (a one-rank communicator: the same call path, for tests)
+            _roctx.push("reni.step.exchange")
+            cur = torch.cuda.current_stream(self.flat.device)
+            if self._comm_ev is not None:
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(cur)
+            if self.overlap_comm and not self.film:
+                # layers >= 2 + head: behind the library's event, on the communication stream (it runs beside k_reni_dw1); the rest
+                # (first layer 68 %, layer 1) here, behind the whole call.  Two slices of one buffer: the same sums as one call.
+                n0 = self._n_head
+                self._comm_stream.wait_event(self._ev_rest)
+                with torch.cuda.stream(self._comm_stream):
+                    self._allreduce(dparams[n0:])
+                    self._ev_comm_done.record(self._comm_stream)
+                self._allreduce(dparams[:n0])
+                cur.wait_event(self._ev_comm_done)
             else:
-                torch.distributed.all_reduce(dparams, op=torch.distributed.ReduceOp.SUM)
-        elif self.train_decoder and self.comm is not None:  # (a one-rank communicator: the same call path, for tests)
-            self.comm.allreduce_(dparams, 1.0)
+                self._allreduce(dparams)
+            if self._comm_ev is not None:
+                eb.record(cur)
+                self._comm_ev.append((ea, eb))
+            _roctx.pop()
         # dense Adam over the whole (owned) latent table, as the reference does (rows outside the batch have zero gradient but
         # still move by momentum -- SURVEY.md Appendix B9); decoder and latent table in ONE launch (reni_adam_step2), as at N = 1
+        _roctx.push("reni.step.adam")
         if self.train_decoder:
             ops.adam_step2(self.flat, dparams, self.m_dec, self.v_dec, self.latent.data, dZ, idx, self.m_lat, self.v_lat,
                            self.t, self.lr, grad_scale=inv_w)
         else:
             ops.adam_rows_step(self.latent.data, dZ, idx, self.m_lat, self.v_lat, self.t, self.lr, grad_scale=inv_w)
+        _roctx.pop()
         return terms

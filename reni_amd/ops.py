@@ -53,6 +53,7 @@ class Plan:
         self.n_params = int(lib.reni_param_count(self._h))
         self.n_map_params = int(lib.reni_film_map_param_count(self._h))
         self.in_features = int(lib.reni_in_features(self._h))
+        self.n_first = hidden_features * self.in_features + hidden_features   # W0 + b0: the head of the flat buffer
         self._ws = {}
 
     def __del__(self):
@@ -85,6 +86,17 @@ class Plan:
         info = (ctypes.c_int32 * 4)()
         _lib.check(self.lib.reni_launch_info(self._h, B, P, info))
         return {"workgroups": info[0], "threads": info[1], "lds_bytes": info[2], "tiles": info[3]}
+
+    def path_info(self, B: int, P: int, need_dw: bool = True, need_dz: bool = True):
+        """Which kernels a backward call of this shape takes (reni_path_info): printed by bench.py so that an environment selector
+        left set by accident shows on the line."""
+        info = (ctypes.c_int32 * 8)()
+        flags = (_lib.NEED_DW if need_dw else 0) | (_lib.NEED_DZ if need_dz else 0)
+        _lib.check(self.lib.reni_path_info(self._h, B, P, flags, info))
+        env = [n for b, n in ((1, "RENI_NO_PERSIST"), (2, "RENI_NO_SIDE_STREAM"), (4, "RENI_FRAG_WS_CAP_MB"), (8, "RENI_DW1_OLD")) if info[6] & b]
+        return {"persistent_kernels": bool(info[0]), "dw1_kernel": ("none", "k_reni_dw1_ring", "k_reni_dw1")[info[1]],
+                "side_stream": bool(info[2]), "images_per_chunk": info[3], "operand_stream": bool(info[4]),
+                "fragment_stream": ("none", "bf16", "f32")[info[5]], "env_overrides": env, "workgroups": info[7]}
 
     # ---- compute
     def _grid_args(self, Z, D):
@@ -497,3 +509,8 @@ def minmax_normalise(img: torch.Tensor, minmax):
         _lib.check(lib.reni_minmax_normalise(x.numel(), x.data_ptr(), float(minmax[0]), float(minmax[1]), out.data_ptr(), wp, wn,
                                              torch.cuda.current_stream(x.device).cuda_stream))
     return out
+
+
+def launch_count(reset: bool = False) -> int:
+    """Kernel launches the library has issued so far in this process (reni_launch_count)."""
+    return int(_lib.load().reni_launch_count(1 if reset else 0))

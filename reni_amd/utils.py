@@ -33,14 +33,10 @@ def get_sineweight(sidelen):
     return torch.sin(phi).unsqueeze(1).repeat(1, 3).unsqueeze(0)
 
 
-def get_mask(sidelen, path):
-    """Inpainting mask PNG -> [1, P, 3] in {0,1}, nearest-neighbour resized to (sidelen/2, sidelen)
-    (utils.py:81-91; torchvision's Resize(NEAREST) restated with PIL/torch: source index =
-    floor(dst * src/dst_size))."""
-    from PIL import Image
-
-    img = np.asarray(Image.open(path))
-    m = torch.from_numpy(img.astype(np.float32) / 255.0)
+def mask_from_array(sidelen, img):
+    """A mask image already in memory (uint8 [Hs, Ws] or [Hs, Ws, C]) -> [1, P, 3] in {0,1}: the part of ``get_mask`` behind
+    ``Image.open``."""
+    m = torch.from_numpy(np.asarray(img).astype(np.float32) / 255.0)
     if m.ndim == 2:
         m = m.unsqueeze(-1)
     if m.shape[-1] == 1:
@@ -51,6 +47,15 @@ def get_mask(sidelen, path):
     ri = torch.clamp((torch.arange(ht, dtype=torch.float32) * (hs / ht)).floor().long(), max=hs - 1)
     ci = torch.clamp((torch.arange(wt, dtype=torch.float32) * (ws / wt)).floor().long(), max=ws - 1)
     return m[ri][:, ci].reshape(-1, 3).unsqueeze(0)
+
+
+def get_mask(sidelen, path):
+    """Inpainting mask PNG -> [1, P, 3] in {0,1}, nearest-neighbour resized to (sidelen/2, sidelen)
+    (utils.py:81-91; torchvision's Resize(NEAREST) restated with PIL/torch: source index =
+    floor(dst * src/dst_size))."""
+    from PIL import Image
+
+    return mask_from_array(sidelen, np.asarray(Image.open(path)))
 
 
 def sRGB(imgs):

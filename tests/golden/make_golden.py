@@ -446,8 +446,131 @@ def g13():
          cam=cam.numpy(), shininess=np.float32(shin), kd=np.float32(kd), **outs)
 
 
+# ---------------------------------------------------------------- G14 / G15 long trajectories at the bench architecture
+def _smooth_images(N, Himg, Wimg, seed):
+    """Smooth synthetic environment maps in [-1, 1] (a few low-order harmonics of the direction per channel, random per image):
+    something a SIREN can actually fit, so that the loss curve falls over hundreds of steps instead of sitting on a noise floor."""
+    g = torch.Generator().manual_seed(seed)
+    D = ref_utils.get_directions(Wimg)[0]                      # [P, 3]
+    th = torch.atan2(D[:, 0], D[:, 2]); y = D[:, 1]
+    basis = torch.stack([torch.ones_like(y), y, D[:, 0], D[:, 2], y * y, torch.sin(2 * th) * (1 - y * y), torch.cos(2 * th) * (1 - y * y),
+                         y * D[:, 0], y * D[:, 2], torch.sin(3 * th) * (1 - y * y), torch.cos(3 * th) * (1 - y * y), y * y * y], 1)  # [P, 12]
+    coef = torch.randn(N, 3, basis.shape[1], generator=g) * torch.tensor([0.3, 0.5, 0.4, 0.4, 0.3, 0.3, 0.3, 0.25, 0.25, 0.2, 0.2, 0.2])
+    img = torch.tanh(torch.einsum("nck,pk->ncp", coef, basis))  # [N, 3, P]
+    return img.reshape(N, 3, Himg, Wimg).contiguous()
+
+
+def _c2_decoder():
+    """The config-2 decoder g4_c2shape.npz already carries (seed 42, N = 2): G14 / G15 start from ITS weights, so neither fixture
+    stores another megabyte of state dict (tests read `sd.net.*` from g4_c2shape.npz)."""
+    torch.manual_seed(42)
+    return ref.RENIAutoDecoder(2, 36, "SO2", 128, 5, 3, True, "tanh", 30, 30, False)
+
+
+def g14():
+    """Config-4 re-enactment at the BENCH architecture (examples.ipynb cell 4; RENI_module.py:126-128; loss_functions.py:60-71):
+    ND = 36, 5 x 128, frozen decoder, 3 maps at 64 x 128, the real Mask-3, RENITestLoss(1e-7, 1e-4), Adam(lr 1e-1) on the latents
+    from zero, 200 steps.  Recorded: the loss 4-tuple of steps 0, 10, ..., 190 and 199, the latents after 20, 100 and 200 steps."""
+    src = _c2_decoder()
+    ckpt = {"model." + k: v.clone() for k, v in src.state_dict().items()}
+    N, W = 3, 128
+    m = ref.RENIAutoDecoder(N, 36, "SO2", 128, 5, 3, True, "tanh", 30, 30, True)
+    m.load_state_dict(ckpt)
+    assert float(m.Z.abs().sum()) == 0.0
+    imgs = _smooth_images(N, W // 2, W, 140)
+    mask_img = np.array(Image.open(os.path.join(REF, "data/Masks/Mask-3.png")))
+    chw = torch.from_numpy(mask_img[..., :3].astype(np.float32) / 255.0).permute(2, 0, 1)   # (utils.py:81-91, see g7)
+    mask = torch.nn.functional.interpolate(chw[None], size=(W // 2, W), mode="nearest")[0].permute(1, 2, 0).reshape(1, -1, 3)
+    D1 = ref_utils.get_directions(W); S1 = ref_utils.get_sineweight(W) * mask
+    crit = ref_loss.RENITestLoss(alpha=1e-7, beta=1e-4)
+    t = imgs.permute(0, 2, 3, 1).reshape(N, -1, 3)
+    D = D1.repeat(N, 1, 1); S = S1.repeat(N, 1, 1)
+    idx = torch.arange(N)
+    steps = 200
+
+    def run(autocast):
+        """autocast: the SAME reference code with its linear layers in bf16 (torch.autocast on the CPU) -- what the reference's own
+        arithmetic does to this trajectory at bf16; the tests derive the band of the bf16 HIP kernels from it."""
+        with torch.no_grad():
+            m.Z.zero_()
+        opt = torch.optim.Adam([m.Z], lr=1e-1)
+        rec_at, terms, snaps = [], [], {}
+        for it in range(steps):
+            with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+                Z = m.Z[idx, :, :]
+                out = m(Z, D)
+                opt.zero_grad()
+                tl = crit(out.float(), t, S, Z)
+            tl[0].backward()
+            opt.step()
+            if it % 10 == 0 or it == steps - 1:
+                rec_at.append(it); terms.append([x.item() for x in tl])
+            if it + 1 in (20, 100, 200):
+                snaps[f"Z_after_{it + 1}"] = m.Z.detach().numpy().copy()
+        return rec_at, terms, snaps
+
+    rec_at, terms, snaps = run(False)
+    _, terms_ac, snaps_ac = run(True)
+    snaps.update({k + "_autocast_bf16": v for k, v in snaps_ac.items()})
+    save("g14_c4_trajectory.npz", imgs=imgs.numpy(), mask=mask.numpy(), rec_at=np.array(rec_at), terms=np.array(terms),
+         terms_autocast_bf16=np.array(terms_ac),
+         W=np.int64(W), steps=np.int64(steps), lr=np.float64(1e-1), alpha=np.float64(1e-7), beta=np.float64(1e-4), **snaps)
+
+
+def g15():
+    """Config-2 training at the bench architecture (RENI_module.py:80-146; run.py): N = 8 images at 32 x 64, batches of 4 in loader
+    order, RENITrainLoss, Adam(lr 1e-3) over decoder + latents, 100 steps.  Recorded: the loss of every step, the final latents and
+    norms / head values of every final decoder parameter."""
+    src = _c2_decoder()
+    N, B, W = 8, 4, 64
+    m = ref.RENIAutoDecoder(N, 36, "SO2", 128, 5, 3, True, "tanh", 30, 30, False)
+    m.net.load_state_dict(src.net.state_dict())
+    with torch.no_grad():
+        m.Z.copy_(torch.randn(N, 36, 3, generator=torch.Generator().manual_seed(150)))
+    Z0 = m.Z.detach().clone()
+    net0 = {k: v.clone() for k, v in m.net.state_dict().items()}
+    imgs_all = _smooth_images(N, W // 2, W, 151)
+    D1 = ref_utils.get_directions(W); S1 = ref_utils.get_sineweight(W)
+    crit = ref_loss.RENITrainLoss()
+    steps = 100
+
+    def run(autocast):
+        with torch.no_grad():
+            m.Z.copy_(Z0)
+        m.net.load_state_dict(net0)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        losses = []
+        for it in range(steps):
+            idx_t = torch.arange(B) + (it % (N // B)) * B
+            imgs = imgs_all[idx_t]
+            t = imgs.permute(0, 2, 3, 1).reshape(B, -1, 3)
+            D = D1.repeat(B, 1, 1); S = S1.repeat(B, 1, 1)
+            with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+                Z = m.Z[idx_t, :, :]
+                out = m(Z, D)
+                loss = crit(out.float(), t, S)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        return losses, m.Z.detach().numpy().copy()
+
+    losses_ac, Z_final_ac = run(True)
+    losses, _ = run(False)
+    arrs = {}
+    for k, p in m.named_parameters():
+        if k == "Z":
+            continue
+        v = p.detach().numpy()
+        arrs["fn." + k] = np.float64(np.linalg.norm(v.astype(np.float64)))
+        arrs["fh." + k] = v.reshape(-1)[:32].copy()
+    save("g15_c2_trajectory.npz", imgs=imgs_all.numpy(), Z0=Z0.numpy(), losses=np.array(losses), Z_final=m.Z.detach().numpy(),
+         losses_autocast_bf16=np.array(losses_ac), Z_final_autocast_bf16=Z_final_ac,
+         W=np.int64(W), B=np.int64(B), steps=np.int64(steps), lr=np.float64(1e-3), **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for w in which:
         globals()[w]()

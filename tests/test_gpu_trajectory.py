@@ -1,0 +1,151 @@
+"""Long optimisation trajectories at the BENCH architecture (ND = 36, 5 x 128) against the reference's own runs (goldens G14, G15):
+what the single-step parity tests cannot show -- whether the bf16 persistent kernels (the ones bench.py times) TRACK the reference's
+loss curve when their per-step gradient error (<= 6.5e-3 rel-L2) goes through Adam's normalisation hundreds of times.
+
+G14 = BASELINE config 4 in the small: frozen decoder, 3 maps at 64 x 128, the real Mask-3, RENITestLoss(1e-7, 1e-4), Adam(lr 0.1) on
+      the latents from zero, 200 steps (examples.ipynb cell 4; RENI_module.py:126-128; loss_functions.py:60-71).
+G15 = BASELINE config 2 in the small: 8 images at 32 x 64, batches of 4, RENITrainLoss, Adam(lr 1e-3) over decoder + latents, 100 steps.
+
+Both fixtures also carry the SAME reference code run under torch.autocast(bfloat16) on the CPU ("the reference's own arithmetic at
+bf16").  The bf16 band asserted here is derived from it: at every recorded step the HIP bf16 loss may deviate from the reference's fp32
+loss by at most max(FLOOR, 1.5 x the autocast run's own deviation at that step), never more than CAP.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import load_golden
+
+pytestmark = pytest.mark.gpu
+
+FLOOR, CAP = 2e-3, 1.5e-2       # relative to the reference loss at that step
+F32_BAND = 1e-3                 # fp32 kernels: relative deviation of every recorded loss
+
+
+def _decoder_sd():
+    g4 = load_golden("g4_c2shape.npz")   # seed-42 config-2 decoder: the weights G14 / G15 start from (make_golden._c2_decoder)
+    return {k[len("sd."):]: torch.from_numpy(v) for k, v in g4.items() if k.startswith("sd.net.")}
+
+
+def _cos(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+
+
+def _band(ref, autocast):
+    dev_ac = np.abs(autocast - ref) / np.abs(ref)
+    return np.minimum(np.maximum(FLOOR, 1.5 * dev_ac), CAP)
+
+
+def _run_g14(dtype, dev):
+    from reni_amd.engine import TrainEngine
+    from reni_amd.models import RENIAutoDecoder
+    from reni_amd.utils import get_directions, get_sineweight
+    g = load_golden("g14_c4_trajectory.npz")
+    N, W = g["imgs"].shape[0], int(g["W"])
+    m = RENIAutoDecoder(N, 36, "SO2", 128, 5, 3, True, "tanh", 30.0, 30.0, True)
+    m.load_state_dict({"model." + k: v for k, v in _decoder_sd().items()})
+    assert float(m.Z.detach().abs().sum()) == 0.0
+    m.set_compute_dtype(dtype).to(dev)
+    D = get_directions(W).to(dev)
+    S = (get_sineweight(W) * torch.from_numpy(g["mask"])).to(dev)
+    imgs = torch.from_numpy(g["imgs"]).to(dev)
+    P = D.shape[1]
+    eng = TrainEngine(m, lr=float(g["lr"]), loss_kind="test", alpha=float(g["alpha"]), beta=float(g["beta"]))
+    idx = torch.arange(N, device=dev)
+    tgt = imgs.permute(0, 2, 3, 1).view(N, P, 3)   # the reference's permute + view (RENI_module.py:83-84), never copied
+    terms, snaps = [], {}
+    for it in range(int(g["steps"])):
+        t = eng.step(idx, tgt, S, D)
+        if it in g["rec_at"]:
+            terms.append(t.detach().cpu().double().numpy())
+        if it + 1 in (20, 100, 200):
+            snaps[it + 1] = m.Z.detach().cpu().numpy().copy()
+    return g, np.array(terms), snaps
+
+
+def test_c4_latent_trajectory_f32_g14():
+    dev = torch.device("cuda:0")
+    g, terms, snaps = _run_g14("f32", dev)
+    ref = g["terms"]
+    rel = np.abs(terms[:, 0] - ref[:, 0]) / ref[:, 0]
+    print("G14 f32: max rel loss deviation", rel.max(), "final-latent cos", _cos(snaps[200], g["Z_after_200"]))
+    assert rel.max() <= F32_BAND, rel
+    np.testing.assert_allclose(terms[:, 2], ref[:, 2], rtol=5e-2, atol=1e-7)   # the prior term alpha |Z|^2 follows the latents
+    np.testing.assert_allclose(terms[:, 3], ref[:, 3], rtol=1e-4)
+    assert _cos(snaps[20], g["Z_after_20"]) >= 0.9999
+
+
+def test_c4_latent_trajectory_bf16_g14():
+    """The frozen + statistics instances of the persistent bf16 kernels over 200 Adam(0.1) steps."""
+    dev = torch.device("cuda:0")
+    g, terms, snaps = _run_g14("bf16", dev)
+    ref, ac = g["terms"], g["terms_autocast_bf16"]
+    rel = np.abs(terms[:, 0] - ref[:, 0]) / ref[:, 0]
+    band = _band(ref[:, 0], ac[:, 0])
+    cos = {k: _cos(snaps[k], g[f"Z_after_{k}"]) for k in (20, 100, 200)}
+    cos_ac = {k: _cos(g[f"Z_after_{k}_autocast_bf16"], g[f"Z_after_{k}"]) for k in (20, 100, 200)}
+    print("G14 bf16: rel loss deviation per recorded step", np.array2string(rel, precision=5))
+    print("G14 bf16: band", np.array2string(band, precision=5))
+    print("G14 bf16: latent cos vs reference", cos, "| the reference's own autocast-bf16 run:", cos_ac)
+    assert (rel <= band).all(), (rel, band)
+    # the loss at the end is what the inpainting loop is run for: within 0.5 % of the reference's
+    assert abs(terms[-1, 0] - ref[-1, 0]) <= 5e-3 * ref[-1, 0]
+    # the latents themselves: the landscape of a random-init decoder is flat in many directions (the reference's own bf16 run ends
+    # at cos 0.66), so the bound is relative to that run, with the 0.99 VERDICT r03 asked for where the reference's bf16 run keeps it
+    for k in (20, 100, 200):
+        assert cos[k] >= min(0.99, cos_ac[k]), (k, cos, cos_ac)
+
+
+def _run_g15(dtype, dev):
+    from reni_amd.engine import TrainEngine
+    from reni_amd.models import RENIAutoDecoder
+    from reni_amd.utils import get_directions, get_sineweight
+    g = load_golden("g15_c2_trajectory.npz")
+    N, B, W = g["imgs"].shape[0], int(g["B"]), int(g["W"])
+    m = RENIAutoDecoder(N, 36, "SO2", 128, 5, 3, True, "tanh", 30.0, 30.0, False)
+    sd = {"model." + k: v for k, v in _decoder_sd().items()}
+    sd["model.Z"] = torch.from_numpy(g["Z0"])
+    m.load_state_dict(sd)
+    m.set_compute_dtype(dtype).to(dev)
+    D = get_directions(W).to(dev)
+    S = get_sineweight(W).to(dev)
+    imgs = torch.from_numpy(g["imgs"]).to(dev)
+    P = D.shape[1]
+    eng = TrainEngine(m, lr=float(g["lr"]))
+    losses = []
+    for it in range(int(g["steps"])):
+        idx = torch.arange(B, device=dev) + (it % (N // B)) * B
+        t = eng.step(idx, imgs[idx].permute(0, 2, 3, 1).view(B, P, 3), S, D)
+        losses.append(float(t[0]))
+    return g, np.array(losses), m
+
+
+def test_c2_training_trajectory_f32_g15():
+    dev = torch.device("cuda:0")
+    g, losses, m = _run_g15("f32", dev)
+    rel = np.abs(losses - g["losses"]) / g["losses"]
+    print("G15 f32: max rel loss deviation", rel.max(), "final-latent cos", _cos(m.Z.detach().cpu().numpy(), g["Z_final"]))
+    assert rel.max() <= F32_BAND, rel
+    assert _cos(m.Z.detach().cpu().numpy(), g["Z_final"]) >= 0.99999
+    for k, p in m.named_parameters():
+        if k != "Z":
+            assert abs(float(p.detach().double().norm()) - float(g["fn." + k])) <= 1e-3 * float(g["fn." + k]), k
+
+
+def test_c2_training_trajectory_bf16_g15():
+    """The training instance of the persistent bf16 kernel + k_reni_dw1_ring + the fused Adam over 100 steps."""
+    dev = torch.device("cuda:0")
+    g, losses, m = _run_g15("bf16", dev)
+    ref, ac = g["losses"], g["losses_autocast_bf16"]
+    rel = np.abs(losses - ref) / ref
+    band = _band(ref, ac)
+    cz = _cos(m.Z.detach().cpu().numpy(), g["Z_final"])
+    cz_ac = _cos(g["Z_final_autocast_bf16"], g["Z_final"])
+    print("G15 bf16: rel loss deviation every 10th step", np.array2string(rel[::10], precision=5), "max", rel.max())
+    print("G15 bf16: final-latent cos", cz, "| the reference's own autocast-bf16 run:", cz_ac)
+    assert (rel <= band).all(), (rel, band)
+    assert cz >= 0.99
+    for k, p in m.named_parameters():
+        if k != "Z":
+            assert abs(float(p.detach().double().norm()) - float(g["fn." + k])) <= 5e-3 * float(g["fn." + k]), k

@@ -223,3 +223,38 @@ def test_g13_envmap_shader_oracle_matches_reference(golden, tag, shin, rtol):
     # background pixels (pix_to_face < 0) render black
     bg = torch.from_numpy(g["pix_to_face"]).reshape(-1) < 0
     assert bg.any() and float(ref[:, bg].abs().max()) == 0.0 and float(col[:, bg].abs().max()) == 0.0
+
+
+def _adam(p, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam's update (no amsgrad, no weight decay), in place."""
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.addcdiv_(m / (1 - b1 ** t), (v / (1 - b2 ** t)).sqrt() + eps, value=-lr)
+
+
+def test_g14_g15_trajectories_start_from_the_oracle(golden):
+    """G14 / G15 (the reference's 200- and 100-step runs at the bench architecture): the oracle reproduces the first recorded losses,
+    and 20 oracle steps of G14 (frozen decoder, masked RENITestLoss, Adam on the latents) land on the reference's latents."""
+    g4 = golden("g4_c2shape.npz")
+    spec = O.DecoderSpec(36, "SO2", 128, 5, 3, True, "tanh")
+    params = {k: v for k, v in _sd(g4).items() if k != "Z"}
+    g = golden("g14_c4_trajectory.npz")
+    N, W = g["imgs"].shape[0], int(g["W"])
+    D = O.get_directions(W).expand(N, -1, 3)
+    S = (O.get_sineweight(W) * torch.from_numpy(g["mask"])).expand(N, -1, 3)
+    T = torch.from_numpy(g["imgs"]).permute(0, 2, 3, 1).reshape(N, -1, 3)
+    Z = torch.zeros(N, 36, 3)
+    m, v = torch.zeros_like(Z), torch.zeros_like(Z)
+    rec = {int(s): i for i, s in enumerate(g["rec_at"])}
+    for it in range(20):
+        r = O.fwd_loss_bwd(spec, params, Z, D, T, S, "test", float(g["alpha"]), float(g["beta"]), need_dw=False)
+        if it in rec:
+            np.testing.assert_allclose(r["loss_terms"], g["terms"][rec[it]], rtol=2e-5, atol=1e-9)
+        _adam(Z, r["dZ"], m, v, it + 1, float(g["lr"]))
+    assert float((Z - torch.from_numpy(g["Z_after_20"])).abs().max()) <= 2e-3
+    g = golden("g15_c2_trajectory.npz")
+    B, W = int(g["B"]), int(g["W"])
+    D = O.get_directions(W).expand(B, -1, 3); S = O.get_sineweight(W).expand(B, -1, 3)
+    T = torch.from_numpy(g["imgs"][:B]).permute(0, 2, 3, 1).reshape(B, -1, 3)
+    r = O.fwd_loss_bwd(spec, params, torch.from_numpy(g["Z0"][:B]), D, T, S)
+    assert abs(r["loss_terms"][0] - g["losses"][0]) <= 2e-6 * g["losses"][0]
