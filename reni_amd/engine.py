@@ -42,7 +42,7 @@ class TrainEngine:
         # FiLM-conditioned models (RENI.py:522-858): the optimised buffer is [net | final_layer | mapping_network]
         self.film = self.plan.conditioning == "film"
         self.flat = model._all_flat() if self.film else model._flat_params()
-        assert self.flat.is_cuda, "move the model to the GPU first"
+        # (no device check here: every op the step calls raises RENILibraryError for a CPU tensor -- there is no CPU fallback)
         self.latent = model.Z if hasattr(model, "Z") else model.mu
         self.lr = lr
         self.loss_kind, self.alpha, self.beta = loss_kind, alpha, beta
@@ -115,8 +115,10 @@ class TrainEngine:
         # Latent rows need no communication (dist.py).  FIT_LATENT (frozen decoder): no collective at all.
         if self.train_decoder and (self.world > 1 or self.comm is not None):  # (a one-rank communicator: the same call path, for tests)
             _roctx.push("reni.step.exchange")
-            cur = torch.cuda.current_stream(self.flat.device)
-            if self._comm_ev is not None:
+            timed = self._comm_ev is not None and self.flat.is_cuda
+            if timed or self.overlap_comm:
+                cur = torch.cuda.current_stream(self.flat.device)
+            if timed:
                 ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ea.record(cur)
             if self.overlap_comm and not self.film:
@@ -131,7 +133,7 @@ class TrainEngine:
                 cur.wait_event(self._ev_comm_done)
             else:
                 self._allreduce(dparams)
-            if self._comm_ev is not None:
+            if timed:
                 eb.record(cur)
                 self._comm_ev.append((ea, eb))
             _roctx.pop()

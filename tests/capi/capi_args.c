@@ -1,0 +1,204 @@
+/* Host-only AddressSanitizer run of the C ABI's argument-validation and layout paths.
+ * Plain C against include/reni_hip.h -- the same boundary a reference-side binding sees.  Built by tests/test_capi_asan_cpu.py with
+ * `hipcc --cuda-host-only -fsanitize=address` from the library's own translation units (no device code, no GPU): every entry point
+ * is driven up to the point where it would touch the device -- NULL and out-of-range arguments, every supported width / depth /
+ * conditioning through plan creation, workspace sizing, launch / path reports, the workspace-too-small returns behind the layout
+ * computation.  ASan watches the plan's offset tables, the layout arrays and the info buffers (heap allocated at their exact size).
+ * Prints "capi_args: N checks ok" and exits 0; any unexpected return code is a failure with the library's message. */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "reni_hip.h"
+
+static int n_checks = 0, n_bad = 0;
+#define EXPECT(expr, want)                                                                              \
+  do {                                                                                                  \
+    long long got_ = (long long)(expr);                                                                 \
+    ++n_checks;                                                                                         \
+    if (got_ != (long long)(want)) {                                                                    \
+      ++n_bad;                                                                                          \
+      fprintf(stderr, "%s:%d: %s = %lld, expected %lld (%s)\n", __FILE__, __LINE__, #expr, got_, (long long)(want), reni_last_error()); \
+    }                                                                                                   \
+  } while (0)
+#define EXPECT_TRUE(expr) EXPECT(!!(expr), 1)
+
+static reni_desc desc(int eq, int nd, int H, int L, int dtype, int cond, int ml, int mf) {
+  reni_desc d;
+  memset(&d, 0, sizeof(d));
+  d.equivariance = eq; d.ndims = nd; d.hidden_features = H; d.hidden_layers = L; d.out_features = 3;
+  d.last_layer_linear = 1; d.output_activation = RENI_ACT_TANH; d.first_omega_0 = 30.f; d.hidden_omega_0 = 30.f;
+  d.dtype = dtype; d.conditioning = cond; d.mapping_layers = ml; d.mapping_features = mf;
+  return d;
+}
+
+int main(void) {
+  reni_plan* p = NULL;
+  reni_desc d = desc(RENI_EQ_SO2, 36, 128, 5, RENI_BF16, RENI_COND_CONCAT, 0, 0);
+  /* ---- plan creation: argument errors */
+  EXPECT(reni_plan_create(NULL, &p), RENI_EINVAL);
+  EXPECT(reni_plan_create(&d, NULL), RENI_EINVAL);
+  { reni_desc b = d; b.equivariance = 3; EXPECT(reni_plan_create(&b, &p), RENI_EINVAL); EXPECT_TRUE(p == NULL); }
+  { reni_desc b = d; b.ndims = 0; EXPECT(reni_plan_create(&b, &p), RENI_EINVAL); }
+  { reni_desc b = d; b.ndims = 257; EXPECT(reni_plan_create(&b, &p), RENI_EINVAL); }
+  { reni_desc b = d; b.out_features = 4; EXPECT(reni_plan_create(&b, &p), RENI_EUNSUPPORTED); }
+  { reni_desc b = d; b.hidden_layers = 15; EXPECT(reni_plan_create(&b, &p), RENI_EUNSUPPORTED); }
+  { reni_desc b = d; b.hidden_layers = -1; EXPECT(reni_plan_create(&b, &p), RENI_EUNSUPPORTED); }
+  { reni_desc b = d; b.hidden_features = 96; EXPECT(reni_plan_create(&b, &p), RENI_EUNSUPPORTED); }
+  { reni_desc b = d; b.output_activation = 3; EXPECT(reni_plan_create(&b, &p), RENI_EINVAL); }
+  { reni_desc b = d; b.dtype = 2; EXPECT(reni_plan_create(&b, &p), RENI_EINVAL); }
+  { reni_desc b = d; b.conditioning = 2; EXPECT(reni_plan_create(&b, &p), RENI_EINVAL); }
+  { reni_desc b = desc(RENI_EQ_NONE, 9, 64, 3, RENI_F32, RENI_COND_FILM, 2, 32); EXPECT(reni_plan_create(&b, &p), RENI_EUNSUPPORTED); }
+  { reni_desc b = desc(RENI_EQ_SO2, 9, 64, 3, RENI_F32, RENI_COND_FILM, 9, 32); EXPECT(reni_plan_create(&b, &p), RENI_EUNSUPPORTED); }
+  { reni_desc b = desc(RENI_EQ_SO2, 9, 64, 3, RENI_F32, RENI_COND_FILM, 2, 0); EXPECT(reni_plan_create(&b, &p), RENI_EINVAL); }
+  EXPECT_TRUE(strlen(reni_last_error()) > 0);
+  /* NULL plans */
+  EXPECT(reni_param_count(NULL), 0);
+  EXPECT(reni_in_features(NULL), 0);
+  EXPECT(reni_workspace_bytes(NULL, 1, 1, 0), 0);
+  EXPECT(reni_film_map_param_count(NULL), 0);
+  reni_plan_destroy(NULL);
+
+  /* ---- every width x depth x dtype x invariance: offsets, layouts, reports (heap buffers of the exact size: ASan sees an overrun) */
+  const int Hs[4] = {32, 64, 128, 256};
+  const int Ls[5] = {0, 1, 5, 6, 14};
+  for (int eq = 0; eq <= 2; ++eq)
+    for (int hi = 0; hi < 4; ++hi)
+      for (int li = 0; li < 5; ++li)
+        for (int dt = 0; dt <= 1; ++dt) {
+          reni_desc c = desc(eq, eq == 0 ? 4 : 36, Hs[hi], Ls[li], dt, RENI_COND_CONCAT, 0, 0);
+          EXPECT(reni_plan_create(&c, &p), RENI_OK);
+          if (!p) continue;
+          const int nd = c.ndims, H = Hs[hi], L = Ls[li];
+          const int F = eq == RENI_EQ_SO2 ? 2 * nd + nd * nd + 2 : eq == RENI_EQ_SO3 ? nd + nd * nd : 4 * nd;
+          EXPECT(reni_in_features(p), F);
+          EXPECT(reni_param_count(p), (long long)H * F + H + (long long)L * (H * H + H) + 3 * H + 3);
+          const int64_t Bs[3] = {1, 7, 64}, Ps[3] = {1, 129, 32768};
+          for (int bi = 0; bi < 3; ++bi)
+            for (int pi = 0; pi < 3; ++pi)
+              for (uint32_t fl = 0; fl <= 3; ++fl) {
+                EXPECT_TRUE(reni_workspace_bytes(p, Bs[bi], Ps[pi], fl) > 0);
+                int32_t* i4 = (int32_t*)malloc(4 * sizeof(int32_t));
+                int32_t* i8 = (int32_t*)malloc(8 * sizeof(int32_t));
+                EXPECT(reni_launch_info(p, Bs[bi], Ps[pi], i4), RENI_OK);
+                EXPECT(reni_path_info(p, Bs[bi], Ps[pi], fl, i8), RENI_OK);
+                EXPECT_TRUE(i4[0] >= 1 && i4[3] == Bs[bi] * ((Ps[pi] + 127) / 128) && i8[6] == 0 && i8[7] >= 1);
+                EXPECT_TRUE(i8[3] >= 1 && i8[3] <= Bs[bi]);
+                free(i4); free(i8);
+              }
+          EXPECT(reni_workspace_bytes(p, 0, 128, 0), 0);
+          EXPECT(reni_workspace_bytes(p, 1, 0, 0), 0);
+          EXPECT(reni_launch_info(p, 1, 128, NULL), RENI_EINVAL);
+          EXPECT(reni_path_info(p, 1, 128, 3, NULL), RENI_EINVAL);
+          EXPECT(reni_path_info(p, 0, 128, 3, (int32_t*)&d), RENI_EINVAL);
+          reni_plan_destroy(p);
+          p = NULL;
+        }
+  /* FiLM with a mapping network: the mapping offsets (MAX_MAP_LAYERS + 1 entries) and the glue layout */
+  for (int ml = 1; ml <= 8; ++ml) {
+    reni_desc c = desc(RENI_EQ_SO2, 36, 128, 5, RENI_BF16, RENI_COND_FILM, ml, 128);
+    EXPECT(reni_plan_create(&c, &p), RENI_OK);
+    if (!p) continue;
+    const long long M_in = 36 * 36 + 36, N_out = 2 * 6 * 128;
+    EXPECT(reni_film_map_param_count(p), (M_in * 128 + 128) + (long long)(ml - 1) * (128 * 128 + 128) + (128 * N_out + N_out));
+    EXPECT_TRUE(reni_workspace_bytes(p, 64, 32768, 3) > 0);
+    reni_plan_destroy(p);
+    p = NULL;
+  }
+
+  /* ---- compute entry points: rejected before anything touches the device */
+  EXPECT(reni_plan_create(&d, &p), RENI_OK);
+  float* fake = (float*)(uintptr_t)0x10000;   /* never dereferenced on the host: device pointers as far as the ABI is concerned */
+  void* ws = (void*)(uintptr_t)0x20000;       /* 256-byte aligned */
+  int64_t st[3] = {3 * 128, 3, 1};
+  float terms[4];
+  EXPECT(reni_forward(NULL, 1, 128, fake, fake, 0, fake, fake, ws, 1 << 20, NULL), RENI_EINVAL);
+  EXPECT(reni_forward(p, 0, 128, fake, fake, 0, fake, fake, ws, 1 << 20, NULL), RENI_EINVAL);
+  EXPECT(reni_forward(p, 1, 0, fake, fake, 0, fake, fake, ws, 1 << 20, NULL), RENI_EINVAL);
+  EXPECT(reni_forward(p, 1, 128, NULL, fake, 0, fake, fake, ws, 1 << 20, NULL), RENI_EINVAL);
+  EXPECT(reni_forward(p, 1, 128, fake, NULL, 0, fake, fake, ws, 1 << 20, NULL), RENI_EINVAL);
+  EXPECT(reni_forward(p, 1, 128, fake, fake, 0, NULL, fake, ws, 1 << 20, NULL), RENI_EINVAL);
+  EXPECT(reni_forward(p, 1, 128, fake, fake, 0, fake, NULL, ws, 1 << 20, NULL), RENI_EINVAL);
+  EXPECT(reni_forward(p, 1, 128, fake, fake, 0, fake, fake, NULL, 0, NULL), RENI_EWORKSPACE);
+  EXPECT(reni_forward(p, 1, 128, fake, fake, 0, fake, fake, (char*)ws + 8, 1 << 20, NULL), RENI_EINVAL);
+  EXPECT(reni_forward(p, 1, 128, fake, fake, 0, fake, fake, ws, 16, NULL), RENI_EWORKSPACE);
+  EXPECT(reni_forward(p, (int64_t)1 << 40, 128, fake, fake, 0, fake, fake, ws, 16, NULL), RENI_EINVAL);
+  EXPECT(reni_forward_loss_backward(p, 2, 256, fake, fake, 0, fake, NULL, st, fake, st, RENI_LOSS_MSE, 0.f, 0.f, 3, NULL, terms, fake, fake,
+                                    ws, 16, NULL), RENI_EINVAL);
+  EXPECT(reni_forward_loss_backward(p, 2, 256, fake, fake, 0, fake, fake, st, fake, st, 7, 0.f, 0.f, 3, NULL, terms, fake, fake, ws, 16,
+                                    NULL), RENI_EINVAL);
+  EXPECT(reni_forward_loss_backward(p, 2, 256, fake, fake, 0, fake, fake, st, fake, st, RENI_LOSS_MSE, 0.f, 0.f, 3, NULL, NULL, fake, fake,
+                                    ws, 16, NULL), RENI_EINVAL);
+  EXPECT(reni_forward_loss_backward(p, 2, 256, fake, fake, 0, fake, fake, st, fake, st, RENI_LOSS_MSE, 0.f, 0.f, RENI_NEED_DW, NULL, terms,
+                                    fake, NULL, ws, 16, NULL), RENI_EINVAL);
+  EXPECT(reni_forward_loss_backward(p, 2, 256, fake, fake, 0, fake, fake, st, fake, st, RENI_LOSS_MSE, 0.f, 0.f, RENI_NEED_DZ, NULL, terms,
+                                    NULL, fake, ws, 16, NULL), RENI_EINVAL);
+  EXPECT(reni_forward_loss_backward(p, 2, 256, fake, fake, 0, fake, fake, st, fake, st, RENI_LOSS_TEST, 1e-7f, 1e-4f, 3, NULL, terms, fake,
+                                    fake, ws, 16, NULL), RENI_EWORKSPACE);
+  EXPECT(reni_forward_loss_backward_rows(p, 2, 256, fake, 10, NULL, fake, 0, fake, fake, st, fake, st, RENI_LOSS_MSE, 0.f, 0.f, 3, NULL,
+                                         terms, fake, fake, ws, 16, NULL), RENI_EINVAL);
+  EXPECT(reni_forward_loss_backward_rows(p, 2, 256, fake, 0, (const int64_t*)fake, fake, 0, fake, fake, st, fake, st, RENI_LOSS_MSE, 0.f,
+                                         0.f, 3, NULL, terms, fake, fake, ws, 16, NULL), RENI_EINVAL);
+  EXPECT(reni_backward(p, 2, 256, fake, fake, 0, fake, NULL, 3, fake, fake, ws, 16, NULL), RENI_EINVAL);
+  EXPECT(reni_backward(p, 2, 256, fake, fake, 0, fake, fake, 3, fake, fake, ws, 16, NULL), RENI_EWORKSPACE);
+  /* a concat plan through the FiLM entry points, and the other way round */
+  EXPECT(reni_film_forward(p, 1, 128, fake, 0, fake, fake, fake, fake, ws, 1 << 20, NULL), RENI_EINVAL);
+  EXPECT(reni_film_model_forward(p, 1, 128, fake, fake, 0, fake, fake, fake, ws, 1 << 20, NULL), RENI_EINVAL);
+  reni_plan_destroy(p);
+  { reni_desc c = desc(RENI_EQ_SO3, 9, 64, 3, RENI_F32, RENI_COND_FILM, 2, 32);
+    EXPECT(reni_plan_create(&c, &p), RENI_OK);
+    EXPECT(reni_forward(p, 1, 128, fake, fake, 0, fake, fake, ws, 1 << 20, NULL), RENI_EINVAL);
+    EXPECT(reni_film_forward(p, 1, 128, fake, 0, NULL, fake, fake, fake, ws, 1 << 20, NULL), RENI_EINVAL);
+    EXPECT(reni_film_forward(p, 1, 128, fake, 0, fake, NULL, fake, fake, ws, 1 << 20, NULL), RENI_EINVAL);
+    EXPECT(reni_film_forward(p, 1, 128, fake, 0, fake, fake, fake, fake, ws, 16, NULL), RENI_EWORKSPACE);
+    EXPECT(reni_film_forward_loss_backward(p, 1, 128, fake, 0, fake, fake, fake, fake, st, fake, st, RENI_LOSS_MSE, 0.f, 3, NULL, terms,
+                                           NULL, fake, fake, ws, 16, NULL), RENI_EINVAL);
+    EXPECT(reni_film_model_forward(p, 1, 128, NULL, fake, 0, fake, fake, fake, ws, 1 << 20, NULL), RENI_EINVAL);
+    EXPECT(reni_film_model_forward(p, 1, 128, fake, fake, 0, fake, fake, fake, NULL, 0, NULL), RENI_EWORKSPACE);
+    EXPECT(reni_film_model_forward(p, 1, 128, fake, fake, 0, fake, fake, fake, ws, 16, NULL), RENI_EWORKSPACE);
+    reni_plan_destroy(p); }
+  /* H = 256 training in image chunks: sizing and the chunk count */
+  { reni_desc c = desc(RENI_EQ_SO2, 36, 256, 5, RENI_BF16, RENI_COND_CONCAT, 0, 0);
+    int32_t i8[8];
+    EXPECT(reni_plan_create(&c, &p), RENI_OK);
+    EXPECT(reni_path_info(p, 64, 32768, 3, i8), RENI_OK);
+    EXPECT_TRUE(i8[3] >= 1 && i8[3] < 64 && i8[5] == 1);
+    EXPECT_TRUE(reni_workspace_bytes(p, 64, 32768, 3) < ((size_t)4 << 30));
+    reni_plan_destroy(p); }
+  /* optimiser / exchange / diagnostics */
+  EXPECT(reni_adam_step(NULL, fake, fake, fake, 4, 1e-3f, .9f, .999f, 1e-8f, 1, 1.f, NULL), RENI_EINVAL);
+  EXPECT(reni_adam_step(fake, fake, fake, fake, -1, 1e-3f, .9f, .999f, 1e-8f, 1, 1.f, NULL), RENI_EINVAL);
+  EXPECT(reni_adam_step(fake, fake, fake, fake, 4, 1e-3f, .9f, .999f, 1e-8f, 0, 1.f, NULL), RENI_EINVAL);
+  EXPECT(reni_adam_step(fake, fake, fake, fake, 0, 1e-3f, .9f, .999f, 1e-8f, 1, 1.f, NULL), RENI_OK);
+  EXPECT(reni_adam_rows_step(fake, fake, NULL, 2, 27, fake, fake, 4, 1e-3f, .9f, .999f, 1e-8f, 1, 1.f, NULL), RENI_EINVAL);
+  EXPECT(reni_adam_rows_step(fake, fake, (const int64_t*)fake, 2, 0, fake, fake, 4, 1e-3f, .9f, .999f, 1e-8f, 1, 1.f, NULL), RENI_EINVAL);
+  EXPECT(reni_adam_rows_step(fake, fake, (const int64_t*)fake, 2, 27, fake, fake, 0, 1e-3f, .9f, .999f, 1e-8f, 1, 1.f, NULL), RENI_OK);
+  EXPECT(reni_adam_step2(fake, fake, fake, fake, 4, NULL, fake, (const int64_t*)fake, 2, 27, fake, fake, 4, 1e-3f, .9f, .999f, 1e-8f, 1,
+                         1.f, NULL), RENI_EINVAL);
+  EXPECT(reni_adam_step2(fake, fake, fake, fake, 0, fake, fake, (const int64_t*)fake, 2, 27, fake, fake, 4, 1e-3f, .9f, .999f, 1e-8f, 1,
+                         1.f, NULL), RENI_EINVAL);
+  EXPECT(reni_allreduce_grads(NULL, fake, 4, 1.f, NULL), RENI_EINVAL);
+  EXPECT(reni_rccl_unique_id(NULL), RENI_EINVAL);
+  EXPECT(reni_rccl_comm_create(NULL, 1, 0, NULL), RENI_EINVAL);
+  EXPECT(reni_rccl_comm_destroy(NULL), RENI_OK);
+  EXPECT(reni_set_grad_ready_event(NULL), RENI_OK);
+  EXPECT(reni_profile_enable(0), RENI_OK);
+  { double ms = -1; int64_t n = -1;
+    EXPECT(reni_profile_read(&ms, &n, 1), RENI_OK);
+    EXPECT_TRUE(ms == 0.0 && n == 0);
+    EXPECT(reni_profile_read(NULL, &n, 1), RENI_EINVAL); }
+  EXPECT(reni_selftest_layouts(NULL, 2), RENI_EINVAL);
+  { int32_t mm[2]; EXPECT(reni_selftest_layouts(mm, 1), RENI_EINVAL); }
+  EXPECT_TRUE(reni_launch_count(1) >= 0);
+  EXPECT(reni_launch_count(0), 0);
+  EXPECT(reni_envmap_shade_workspace_bytes(0, 1, 1) == 0 || 1, 1);
+  EXPECT_TRUE(reni_image_workspace_bytes(2, 128, 256) > 0);
+
+  if (n_bad) {
+    fprintf(stderr, "capi_args: %d of %d checks FAILED\n", n_bad, n_checks);
+    return 1;
+  }
+  printf("capi_args: %d checks ok\n", n_checks);
+  return 0;
+}

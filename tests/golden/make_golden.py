@@ -511,6 +511,20 @@ def g14():
 
     rec_at, terms, snaps = run(False)
     _, terms_ac, snaps_ac = run(True)
+    # the latent gradient AT the fp32 trajectory's latents (start, after 20 / 100 / 200 steps), in fp32 and under autocast: a
+    # per-step comparison that does not go through 200 steps of Adam (trajectories diverge near stationarity, gradients do not)
+    grads = {}
+    for name, Zs in [("0", np.zeros_like(snaps["Z_after_20"]))] + [(str(k), snaps[f"Z_after_{k}"]) for k in (20, 100, 200)]:
+        for ac in (False, True):
+            with torch.no_grad():
+                m.Z.copy_(torch.from_numpy(Zs))
+            m.Z.grad = None
+            with torch.autocast("cpu", dtype=torch.bfloat16, enabled=ac):
+                Z = m.Z[idx, :, :]
+                tl = crit(m(Z, D).float(), t, S, Z)
+            tl[0].backward()
+            grads[f"dZ_at_{name}" + ("_autocast_bf16" if ac else "")] = m.Z.grad.detach().float().numpy().copy()
+    snaps.update(grads)
     snaps.update({k + "_autocast_bf16": v for k, v in snaps_ac.items()})
     save("g14_c4_trajectory.npz", imgs=imgs.numpy(), mask=mask.numpy(), rec_at=np.array(rec_at), terms=np.array(terms),
          terms_autocast_bf16=np.array(terms_ac),

@@ -137,3 +137,136 @@ def test_ownership_and_step_counts_of_config_3():
     # bench.py's per-GPU batch: 64 <= the smallest share, so every rank can draw a full batch at every N in {1, 2, 4, 8}
     for w in (1, 2, 4, 8):
         assert min(len(rdist.owned_indices(n, r, w)) for r in range(w)) >= 64
+
+
+# ---- world-8 TrainEngine on the CPU: config 3's code path end to end -----------------------------------
+# The HIP kernels cannot run here, so the engine's two device calls are replaced BY THE TEST with the oracle (test infrastructure:
+# the product has no such path): the fused fwd+loss+bwd by oracle.fwd_loss_bwd, the fused Adam by the formula of torch.optim.Adam.
+# Everything else is the product's: ownership, the gather of the batch's rows, ONE all-reduce(sum) of the flat gradient, the 1 / W on
+# Adam's grad_scale, the dense latent Adam, short last batches.
+N8, B8, W8 = 615, 64, 8
+SPEC8 = dict(ndims=2, equivariance="SO2", hidden_features=8, hidden_layers=1)
+
+
+class _OraclePlan:
+    conditioning = "concat"
+
+    def __init__(self):
+        from oracle import reni_oracle as O
+        self.O = O
+        self.spec = O.DecoderSpec(SPEC8["ndims"], SPEC8["equivariance"], SPEC8["hidden_features"], SPEC8["hidden_layers"], 3, True, "tanh")
+        self.hidden_features, self.hidden_layers = SPEC8["hidden_features"], SPEC8["hidden_layers"]
+
+    def forward_loss_backward(self, Z, D, flat, target, weight, loss_kind="mse", alpha=0.0, beta=0.0, need_dw=True, need_dz=True,
+                              want_out=False, idx=None):
+        from tests.util import unflatten
+        params = unflatten(self.spec, flat.detach().clone())
+        Zb = Z[idx] if idx is not None else Z
+        B, P = Zb.shape[0], D.shape[1]
+        r = self.O.fwd_loss_bwd(self.spec, params, Zb, D.expand(B, P, 3), target, weight.expand(B, P, 3), loss_kind, alpha, beta)
+        dp = torch.cat([r["grads"][k].reshape(-1) for k in self.spec.param_keys()])
+        return torch.tensor(r["loss_terms"]), r["dZ"], dp, None
+
+
+class _TorchAdamOps:
+    """ops.adam_step2 / adam_rows_step restated with torch on the CPU (torch.optim.Adam's update; dense over the latent table)."""
+    @staticmethod
+    def _adam(p, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8):
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        p.addcdiv_(m / (1 - b1 ** t), (v / (1 - b2 ** t)).sqrt() + eps, value=-lr)
+
+    @classmethod
+    def adam_step2(cls, p, g, m, v, table, g_rows, idx, tm, tv, step, lr, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        cls._adam(p, g * grad_scale, m, v, step, lr)
+        cls.adam_rows_step(table, g_rows, idx, tm, tv, step, lr, grad_scale=grad_scale)
+
+    @classmethod
+    def adam_rows_step(cls, table, g_rows, idx, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        dense = torch.zeros_like(table).index_add_(0, idx, g_rows * grad_scale)
+        cls._adam(table, dense, m, v, step, lr)
+
+
+class _TinyModel:
+    """What TrainEngine touches of a RENIAutoDecoder: the flat decoder buffer, the latent table, the plan."""
+    fixed_decoder = False
+
+    def __init__(self, rows):
+        from oracle import reni_oracle as O
+        from tests.util import flat_params
+        plan = _OraclePlan()
+        self._p = plan
+        self._flat = flat_params(plan.spec, O.init_params(plan.spec, torch.Generator().manual_seed(8))).clone()
+        self.Z = torch.nn.Parameter(torch.stack([torch.randn(SPEC8["ndims"], 3, generator=torch.Generator().manual_seed(1000 + r)) for r in rows]))
+
+    def _plan(self):
+        return self._p
+
+    def _flat_params(self):
+        return self._flat
+
+
+def _data8(rows):
+    from oracle import reni_oracle as O
+    D, S = O.get_directions(8), O.get_sineweight(8)            # 4 x 8 = 32 directions
+    T = torch.stack([torch.rand(D.shape[1], 3, generator=torch.Generator().manual_seed(5000 + r)) * 2 - 1 for r in rows])
+    return D, S, T
+
+
+def _engine8_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        torch.set_num_threads(1)
+        rdist.init_from_env(backend="gloo")
+        from reni_amd import engine
+        engine.ops = _TorchAdamOps                      # (the test's stand-ins for the two device calls, see above)
+        rows = rdist.owned_indices(N8, rank, world)
+        m = _TinyModel(rows)
+        D, S, T = _data8(rows)
+        eng = engine.TrainEngine(m, lr=1e-2)
+        assert eng.world == world
+        local = {r: k for k, r in enumerate(rows)}
+        batches = rdist.epoch_batches(N8, B8, rank, world)
+        for b in batches:                               # one epoch: 64 images, then the short rest (12 or 13)
+            idx = torch.tensor([local[i] for i in b])
+            eng.step(idx, T[idx], S, D)
+        q.put((rank, m._flat_params().numpy().copy(), m.Z.detach().numpy().copy(), [len(b) for b in batches]))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc(), None, None))
+
+
+def test_world8_train_engine_epoch_equals_one_process_on_the_union_batches():
+    """BASELINE config 3's partition through TrainEngine.step on 8 gloo ranks: 615 images, owners i % 8 with 76-77 images each, two
+    steps per epoch (64, then 12-13 images per rank).  Every rank ends with the same decoder, and decoder + latents equal one process
+    stepping on the UNION of the ranks' batches with every gradient scaled 1/8 (the reference's DDP mean, run.py:97)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_engine8_worker, args=(r, W8, port, q)) for r in range(W8)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert not isinstance(r[1], str), r[1]
+    assert all(r[3][0] == 64 and r[3][1] in (12, 13) and len(r[3]) == 2 for r in res)
+    for r in res[1:]:
+        assert (r[1] == res[0][1]).all(), "ranks ended with different decoders"
+    # one process: the union batch of every step, gradients / 8
+    rows = list(range(N8))
+    m = _TinyModel(rows)
+    D, S, T = _data8(rows)
+    flat, lat = m._flat_params(), m.Z.data
+    md, vd, ml, vl = torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros_like(lat), torch.zeros_like(lat)
+    per_rank = [rdist.epoch_batches(N8, B8, r, W8) for r in range(W8)]
+    for t in range(2):
+        idx = torch.tensor(sorted(i for r in range(W8) for i in per_rank[r][t]))
+        _, dZ, dp, _ = m._plan().forward_loss_backward(lat, D, flat, T[idx], S, idx=idx)
+        _TorchAdamOps.adam_step2(flat, dp, md, vd, lat, dZ, idx, ml, vl, t + 1, 1e-2, grad_scale=1.0 / W8)
+    assert float((torch.from_numpy(res[0][1]) - flat).abs().max()) <= 2e-5 * float(flat.abs().max())
+    for r in res:
+        own = rdist.owned_indices(N8, r[0], W8)
+        assert float((torch.from_numpy(r[2]) - lat[own]).abs().max()) <= 2e-5

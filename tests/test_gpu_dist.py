@@ -68,6 +68,67 @@ def _worker_body(rank, world, port, q):
     torch.distributed.destroy_process_group()
 
 
+def _overlap_worker(rank, world, port, q):
+    """TrainEngine(overlap_comm=True) against the plain exchange, on the persistent bf16 kernels (where the library's 'layers >= 2
+    are final' event sits in FRONT of k_reni_dw1) and on the generic fp32 path (where it is recorded at the end)."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank), RENI_SHARE_GPU="1", RENI_DIST_BACKEND="gloo")
+        from reni_amd import dist as rdist
+        from reni_amd.engine import TrainEngine
+        from reni_amd.models import RENIAutoDecoder
+        rdist.init_from_env()
+        dev = torch.device("cuda:0")
+        rows = rdist.owned_indices(N_IMG, rank, world)
+        D, S, T = _data(rows, dev)
+        out = {}
+        for dtype, H, L in (("bf16", 128, 3), ("f32", 64, 3)):
+            for overlap in (False, True):
+                torch.manual_seed(0)
+                m = RENIAutoDecoder(len(rows), 9, "SO2", H, L, 3, True, "tanh", 30, 30, False)
+                with torch.no_grad():
+                    for k, r in enumerate(rows):
+                        m.Z[k] = torch.randn(9, 3, generator=torch.Generator().manual_seed(100 + r))
+                m.set_compute_dtype(dtype).to(dev)
+                eng = TrainEngine(m, lr=LR, overlap_comm=overlap)
+                assert eng.overlap_comm == overlap
+                eng.time_comm(True)
+                idx = torch.arange(len(rows), device=dev)
+                for _ in range(3):
+                    eng.step(idx, T, S, D)
+                us = eng.time_comm(False)
+                assert us is not None and us > 0
+                torch.cuda.synchronize()
+                out[(dtype, overlap)] = (m._flat_params().detach().cpu().numpy(), m.Z.detach().cpu().numpy())
+        q.put((rank, out, None, None))
+        torch.distributed.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc(), None, None))
+
+
+def test_overlapped_exchange_is_bit_equal_to_the_plain_one():
+    """the all-reduce of layers >= 2 + head started behind reni_set_grad_ready_event on a communication
+    stream, the rest behind the call -- two slices of one buffer, so decoder and latents must equal the one-collective step's bit
+    for bit, on both ranks, for the persistent and the generic path."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert not isinstance(r[1], str), r[1]
+    for dtype in ("bf16", "f32"):
+        for r in res:
+            a, b = r[1][(dtype, False)], r[1][(dtype, True)]
+            assert (a[0] == b[0]).all() and (a[1] == b[1]).all(), (dtype, r[0])
+        assert (res[0][1][(dtype, True)][0] == res[1][1][(dtype, True)][0]).all()   # both ranks: the same decoder
+
+
 def test_two_rank_step_equals_one_rank_step_on_the_union_batch():
     from reni_amd import ops
     ctx = mp.get_context("spawn")
@@ -139,11 +200,24 @@ def test_bench_default_line_carries_every_baseline_config_and_the_capi_exchange(
     in the same process, each with its own roofline; and `--comm capi` routes the step's exchange through
     the C ABI's reni_allreduce_grads (here a one-rank communicator: the same call path as N > 1)."""
     line = _run_bench({}, "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
-    assert set(line["also"]) == {"c4", "c5", "film", "c2_b100"} and line["also"]["c2_b100"]["images_per_gpu_per_step"] == 100
-    for c, flop in (("c4", 348448), ("c5", 177860), ("film", 424480)):
+    curric = {"c2_curric_16x32", "c2_curric_32x64", "c2_curric_64x128"}   # configs/experiment.yaml:29-34, B = 100
+    assert set(line["also"]) == {"c4", "c5", "film", "c2_b100", "c2_h256"} | curric, {k: v.get("error") for k, v in line["also"].items()}
+    assert all("error" not in v for v in line["also"].values()), {k: v.get("error") for k, v in line["also"].items()}
+    assert line["also"]["c2_b100"]["images_per_gpu_per_step"] == 100
+    for c, flop in (("c4", 348448), ("c5", 177860), ("film", 424480), ("c2_h256", 2028320)):
         r = line["also"][c]
         assert r["value"] > 0 and r["ms_per_step"] > 0 and r["roofline"]["flop_per_sample"] == flop and r["roofline"]["kernel_avg_ms"] > 0
+    for c in curric:
+        r = line["also"][c]
+        assert r["images_per_gpu_per_step"] == 100 and r["launches_per_step"] >= 2 and r["paths"]["env_overrides"] == []
+    assert line["also"]["c5"]["so3"]["value"] > 0            # SURVEY 8(d) C5: both invariances
     assert line["roofline"]["flop_per_sample"] == 522784 and "also" not in line["also"]["c4"]
+    # ONE definition of the headline (ADVICE r03): the contract's W + K window, first; the sustained-clock re-run is a side field
+    assert line["steps"] == 3 and line["warmup"] == 1 and line["sustained"]["steps"] == 3 and "from_idle" not in line
+    assert line["config"]["paths"]["dw1_kernel"] == "k_reni_dw1_ring" and line["config"]["paths"]["env_overrides"] == []
+    assert line["launches_per_step"] == int(line["launches_per_step"]) and 2 <= line["launches_per_step"] <= 16
+    forced = _run_bench({"RENI_DW1_OLD": "1"}, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-also")
+    assert forced["config"]["paths"]["dw1_kernel"] == "k_reni_dw1" and forced["config"]["paths"]["env_overrides"] == ["RENI_DW1_OLD"]
     capi = _run_bench({}, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--comm", "capi")
     assert "also" not in capi and capi["config"]["exchange_step"].startswith("reni_allreduce_grads") and capi["value"] > 0
 
