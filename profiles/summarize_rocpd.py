@@ -19,12 +19,12 @@ def main():
     # kernel in the process (argument 3 = K) -- their average is what the bench line's kernel_avg_ms must agree with
     if len(sys.argv) > 3:
         k = int(sys.argv[3])
-        last = c.execute(f"select end-start from kernels where {name_col} like '%k_reni_train_bf16<128, true, false, false>%' "
+        last = c.execute(f"select end-start from kernels where {name_col} like '%k_reni_train_bf16<128, true, false, false, true>%' "
                          f"order by start desc limit {k}").fetchall()
         if last:
             d = [r[0] for r in last]
             out.append("")
-            out.append(f"headline window: the last {len(d)} launches of `k_reni_train_bf16<128, true, false, false>`: "
+            out.append(f"headline window: the last {len(d)} launches of `k_reni_train_bf16<128, true, false, false, true>`: "
                        f"avg {sum(d)/len(d)/1e3:.1f} us, min {min(d)/1e3:.1f} us, max {max(d)/1e3:.1f} us")
     text = "\n".join(out)
     print(text)
