@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-also", action="store_true", help="skip the c4 / c5 / film sub-records of the default (c2) line")
+    ap.add_argument("--no-fused-step", action="store_true",
+                    help="the training step as two library calls (fwd+loss+bwd, then Adam) instead of reni_train_step_rows")
     ap.add_argument("--comm", default="torch", choices=["torch", "capi"],
                     help="the step's exchange (decoder-gradient all-reduce): torch.distributed's nccl backend, or the C ABI's "
                          "reni_allreduce_grads on an RCCL communicator the library owns")
@@ -285,7 +287,7 @@ def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None,
         if args.comm == "capi" and cfg in ("c2", "film"):  # the exchange step through the C ABI's reni_allreduce_grads
             comm = rdist.RcclComm(rank, world)
         if cfg in ("c2", "film"):
-            eng = TrainEngine(model, lr=1e-5, comm=comm)
+            eng = TrainEngine(model, lr=1e-5, comm=comm, fused_step=not args.no_fused_step)
             weight = sineweight
         else:
             # the notebook's inpainting mask (examples.ipynb cell 4: data/Masks/Mask-3.png, rows 20-92 x columns 81-164 of 128 x 256
@@ -297,7 +299,9 @@ def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None,
             """B consecutive owned images; targets are the reference's permute+view of [B,3,H,W]
             (RENI_module.py:83-84): a channel-planar strided view, never copied."""
             start = (s * B) % (n_local - B + 1)
-            return eng.step(idx_all[start:start + B], imgs[start:start + B].permute(0, 2, 3, 1).view(B, P, 3), weight, directions)
+            nstart = ((s + 1) * B) % (n_local - B + 1)   # (the loader is one batch ahead: the fused step stages that batch's prologue)
+            return eng.step(idx_all[start:start + B], imgs[start:start + B].permute(0, 2, 3, 1).view(B, P, 3), weight, directions,
+                            next_idx=idx_all[nstart:nstart + B])
     else:
         def step(s):
             with torch.no_grad():
@@ -405,6 +409,9 @@ def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, 
                            "avg_us_on_compute_stream": comm_us}
     if args.comm == "capi":
         rec["config"]["exchange_step"] = "reni_allreduce_grads (C ABI, librccl)"
+    if eng is not None and cfg == "c2":
+        rec["config"]["step_call"] = ("reni_train_step_rows (one call: fwd+loss+bwd, Adam, next prologue)" if eng._stage is not None
+                                      else "reni_forward_loss_backward_rows + reni_adam_step2")
     return rec
 
 

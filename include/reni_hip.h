@@ -145,6 +145,26 @@ int reni_forward_loss_backward_rows(const reni_plan* plan, int64_t B, int64_t P,
                                     float* loss_terms, float* dZ, float* dparams, void* workspace, size_t workspace_bytes,
                                     void* stream);
 
+/* One whole training step of the reference's FIT_DECODER loop in one call (RENI_module.py:80-146 training_step, :178-192 the
+ * optimiser over decoder + latent table; run.py's `trainer.fit` iteration): reni_forward_loss_backward_rows with
+ * RENI_NEED_DW | RENI_NEED_DZ, THEN reni_adam_step2 -- same arguments, same results, bit for bit -- in fewer launches:
+ *   - the optimiser step is one launch that also sums layer 1's weight-gradient partials (on the persistent bf16 path their
+ *     reduction is otherwise a launch of its own behind k_reni_dw1);
+ *   - the NEXT batch's prologue (`idx_next`: its latent rows gathered, A_b, layer-0 operands, the packed weight images of the
+ *     UPDATED decoder) is run at the end of this call, so the next call starts with its main kernel.
+ * `stage_state` (in / out, zero before the first call) says whether -- and into which of two copies -- the previous call staged this
+ * call's prologue.  The caller resets it to zero whenever it changes B, P, `params` or `Z_table` between two calls, and passes as
+ * idx what it announced as `idx_next`: the library checks the indices on the device and turns a step whose batch is not the staged one
+ * into NaN (loss and gradients).  idx_next = NULL: nothing is staged (the next call runs its own prologue).  Z_table and params are
+ * updated in place; dZ [B,ND,3] and dparams receive the step's gradients as reni_forward_loss_backward_rows returns them.  Single
+ * process only: a data-parallel step has its all-reduce between the two halves and uses the two separate entry points. */
+int reni_train_step_rows(const reni_plan* plan, int64_t B, int64_t P, float* Z_table, int64_t n_rows, const int64_t* idx,
+                         const int64_t* idx_next, const float* D, int64_t d_batch_stride, float* params, const float* target,
+                         const int64_t target_strides[3], const float* weight, const int64_t weight_strides[3], int32_t loss_kind,
+                         float alpha, float beta, float* m_dec, float* v_dec, float* m_lat, float* v_lat, float lr, float b1,
+                         float b2, float eps, int64_t step, float grad_scale, uint32_t* stage_state, float* loss_terms, float* dZ,
+                         float* dparams, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward for an arbitrary upstream gradient dout[B,P,3] (generic autograd use of
  * model(Z,D)); the forward is recomputed inside the same fused kernel. */
 int reni_backward(const reni_plan* plan, int64_t B, int64_t P, const float* Z, const float* D,

@@ -89,6 +89,7 @@ struct PrepArgs {
   const long long* idx;  // optional: image b's latent is row idx[b] of Z (a latent TABLE); the batch's rows are copied to Zc
   long long n_rows;      // rows of that table: an index outside [0, n_rows) poisons the image's results with NaN
   float* Zc;             // [B][nd][3] compact copy of the gathered rows (read by the epilogue kernels), with idx only
+  long long* idx_copy;   // [B] optional: idx as this prologue saw it (reni_train_step_rows checks a staged batch against it)
   const float* Z;
   const float* W0;
   const float* b0;

@@ -23,7 +23,7 @@ if os.environ.get("RENI_ROCTX"):
 
 class TrainEngine:
     def __init__(self, model, lr: float, loss_kind: str = "mse", alpha: float = 0.0, beta: float = 0.0, comm=None,
-                 overlap_comm: bool = False):
+                 overlap_comm: bool = False, fused_step: bool = True):
         """comm: an optional ``dist.RcclComm``; the decoder-gradient all-reduce then goes through the library's own
         ``reni_allreduce_grads`` on the compute stream instead of torch.distributed's nccl backend (the same RCCL ring
         either way).
@@ -34,6 +34,10 @@ class TrainEngine:
         so it is off by default."""
         self.comm = comm
         self.overlap_comm = overlap_comm
+        # fused_step: one process, trainable concat decoder -> the whole step is ONE library call (reni_train_step_rows: Adam and the
+        # next batch's prologue run beside the backward pass's last kernel; pass the next batch to step(..., next_idx=) to stage it)
+        self.fused_step = fused_step
+        self._stage = None
         self._comm_stream = None
         self._ev_rest = self._ev_comm_done = None
         self._comm_ev = None        # [(start, end)] torch events around the exchange step while time_comm is on
@@ -82,9 +86,31 @@ class TrainEngine:
         else:
             torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM)
 
-    def step(self, idx: torch.Tensor, target: torch.Tensor, weight: torch.Tensor, directions: torch.Tensor):
+    def step(self, idx: torch.Tensor, target: torch.Tensor, weight: torch.Tensor, directions: torch.Tensor, next_idx=None):
         """idx: rows of this rank's latent table in the batch; target/weight: strided [B,P,3] views.
+        next_idx: the NEXT step's idx, if the caller knows it (a loader that is one batch ahead does): the fused step stages that
+        batch's prologue behind this step's backward pass; the next call must then be made with exactly that idx (checked here).
         Returns the device tensor (loss, mse, prior, cosine) of this rank's batch."""
+        if (self.fused_step and not self.film and self.train_decoder and self.world == 1 and self.comm is None
+                and hasattr(self.plan, "train_step")):
+            import ctypes
+            if self._stage is None:
+                self._stage = {"state": ctypes.c_uint32(0), "expect": None, "shape": None}
+            st = self._stage
+            shape = (int(idx.numel()), int(directions.shape[-2]))
+            # (host-side check by identity only -- comparing contents would cost a device synchronisation per step; the library
+            # compares the staged batch's indices with this call's ON THE DEVICE and poisons the step with NaN if they differ)
+            if st["state"].value & 1 and (st["shape"] != shape or st["expect"] != (idx.data_ptr(), idx.numel())):
+                st["state"].value = 0   # another batch than the one announced: this call runs its own prologue
+            self.t += 1
+            _roctx.push("reni.step.fused")
+            nxt = next_idx.contiguous() if next_idx is not None and int(next_idx.numel()) == shape[0] else None
+            terms, _, _ = self.plan.train_step(self.latent.data, idx.contiguous(), directions, self.flat, target, weight, self.m_dec,
+                                               self.v_dec, self.m_lat, self.v_lat, self.t, self.lr, st["state"], idx_next=nxt,
+                                               loss_kind=self.loss_kind, alpha=self.alpha, beta=self.beta)
+            st["expect"], st["shape"] = ((nxt.data_ptr(), nxt.numel()) if nxt is not None else None), shape
+            _roctx.pop()
+            return terms
         _roctx.push("reni.step.fwd_bwd")
         if self.film:  # mapping network + fused core + glue backward in one library call (reni_film_model_*)
             n = self.plan.n_params

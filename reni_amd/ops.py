@@ -177,6 +177,41 @@ class Plan:
             _lib.check(self.lib.reni_forward_loss_backward(self._h, B, P, Z.data_ptr(), *tail))
         return loss_terms, dZ, dparams, out
 
+    def train_step(self, Z_table, idx, D, params, target, weight, m_dec, v_dec, m_lat, v_lat, step, lr, stage_state, idx_next=None,
+                   loss_kind="mse", alpha=0.0, beta=0.0, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        """reni_train_step_rows: fused fwd + loss + bwd on the rows `idx` of the latent TABLE, then torch.optim.Adam's update of
+        `params` and of the whole table, IN PLACE -- the same results as forward_loss_backward(idx=...) + adam_step2, with Adam and
+        the next batch's prologue (`idx_next`) scheduled beside the backward pass's last kernel.  stage_state: a ctypes.c_uint32
+        the caller keeps between calls (zero it whenever params / the table / the shapes change behind the library's back).
+        Returns (loss_terms[4], dZ [B,ND,3], dparams)."""
+        _require_cuda(Z_table, D, params, target, weight, idx, idx_next, m_dec, v_dec, m_lat, v_lat)
+        for t in (Z_table, params, m_dec, v_dec, m_lat, v_lat):
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError("train_step updates its buffers in place: contiguous float32 tensors only")
+        self._check_zp(Z_table, params)
+        for ix in (idx, idx_next):
+            if ix is not None and (ix.dtype != torch.int64 or ix.dim() != 1 or ix.numel() != idx.numel() or not ix.is_contiguous()):
+                raise ValueError("idx / idx_next must be contiguous 1-D int64 tensors of the same length")
+        B, P, Dc, dbs = self._grid_args(Z_table[:1].expand(idx.numel(), -1, -1), D)
+        target = (target if target.dtype == torch.float32 else target.float()).expand(B, P, 3)
+        weight = (weight if weight.dtype == torch.float32 else weight.float()).expand(B, P, 3)
+        ts = (ctypes.c_int64 * 3)(*target.stride())
+        wst = (ctypes.c_int64 * 3)(*weight.stride())
+        dev = Z_table.device
+        loss_terms = torch.empty(4, dtype=torch.float32, device=dev)
+        dZ = torch.empty(B, self.ndims, 3, dtype=torch.float32, device=dev)
+        dparams = torch.empty(self.n_params, dtype=torch.float32, device=dev)
+        ws = self.workspace(B, P, _lib.NEED_DW | _lib.NEED_DZ, dev)
+        wp, wn = self._aligned_ptr(ws)
+        kind = {"mse": _lib.LOSS_MSE, "test": _lib.LOSS_TEST}[loss_kind]
+        _lib.check(self.lib.reni_train_step_rows(
+            self._h, B, P, Z_table.data_ptr(), Z_table.shape[0], idx.data_ptr(), idx_next.data_ptr() if idx_next is not None else None,
+            Dc.data_ptr(), dbs, params.data_ptr(), target.data_ptr(), ts, weight.data_ptr(), wst, kind, float(alpha), float(beta),
+            m_dec.data_ptr(), v_dec.data_ptr(), m_lat.data_ptr(), v_lat.data_ptr(), float(lr), float(betas[0]), float(betas[1]),
+            float(eps), int(step), float(grad_scale), ctypes.byref(stage_state), loss_terms.data_ptr(), dZ.data_ptr(),
+            dparams.data_ptr(), wp, wn, torch.cuda.current_stream(dev).cuda_stream))
+        return loss_terms, dZ, dparams
+
     def backward(self, Z, D, params, dout, need_dw=True, need_dz=True):
         _require_cuda(Z, D, params, dout)
         Z = _f32c(Z); params = _f32c(params); dout = _f32c(dout)

@@ -24,6 +24,9 @@ static int n_checks = 0, n_bad = 0;
   } while (0)
 #define EXPECT_TRUE(expr) EXPECT(!!(expr), 1)
 
+static int64_t g_st3[3] = {3 * 128, 3, 1};
+static const int64_t* st3(uint32_t unused) { (void)unused; return g_st3; }
+
 static reni_desc desc(int eq, int nd, int H, int L, int dtype, int cond, int ml, int mf) {
   reni_desc d;
   memset(&d, 0, sizeof(d));
@@ -140,6 +143,24 @@ int main(void) {
                                          terms, fake, fake, ws, 16, NULL), RENI_EINVAL);
   EXPECT(reni_forward_loss_backward_rows(p, 2, 256, fake, 0, (const int64_t*)fake, fake, 0, fake, fake, st, fake, st, RENI_LOSS_MSE, 0.f,
                                          0.f, 3, NULL, terms, fake, fake, ws, 16, NULL), RENI_EINVAL);
+  { uint32_t st = 3;
+    EXPECT(reni_train_step_rows(p, 2, 256, fake, 10, NULL, NULL, fake, 0, fake, fake, st3(st), fake, st3(st), RENI_LOSS_MSE, 0.f, 0.f, fake, fake,
+                                fake, fake, 1e-3f, .9f, .999f, 1e-8f, 1, 1.f, &st, terms, fake, fake, ws, 16, NULL), RENI_EINVAL);
+    EXPECT(reni_train_step_rows(p, 2, 256, fake, 10, (const int64_t*)fake, NULL, fake, 0, fake, fake, st3(st), fake, st3(st), RENI_LOSS_MSE,
+                                0.f, 0.f, fake, fake, fake, fake, 1e-3f, .9f, .999f, 1e-8f, 0, 1.f, &st, terms, fake, fake, ws, 16, NULL),
+           RENI_EINVAL);
+    EXPECT(reni_train_step_rows(p, 2, 256, fake, 10, (const int64_t*)fake, NULL, fake, 0, fake, fake, st3(st), fake, st3(st), RENI_LOSS_MSE,
+                                0.f, 0.f, NULL, fake, fake, fake, 1e-3f, .9f, .999f, 1e-8f, 1, 1.f, &st, terms, fake, fake, ws, 16, NULL),
+           RENI_EINVAL);
+    EXPECT(reni_train_step_rows(p, 2, 256, fake, 10, (const int64_t*)fake, NULL, fake, 0, fake, fake, st3(st), fake, st3(st), RENI_LOSS_MSE,
+                                0.f, 0.f, fake, fake, fake, fake, 1e-3f, .9f, .999f, 1e-8f, 1, 1.f, NULL, terms, fake, fake, ws, 16, NULL),
+           RENI_EINVAL);
+    EXPECT(reni_train_step_rows(p, 2, 256, fake, 10, (const int64_t*)fake, NULL, fake, 0, fake, fake, st3(st), fake, st3(st), 2, 0.f, 0.f,
+                                fake, fake, fake, fake, 1e-3f, .9f, .999f, 1e-8f, 1, 1.f, &st, terms, fake, fake, ws, 16, NULL), RENI_EINVAL);
+    st = 3;  /* a stale 'staged' state: the call still sizes its layout, finds the workspace too small, and clears the state */
+    EXPECT(reni_train_step_rows(p, 2, 256, fake, 10, (const int64_t*)fake, (const int64_t*)fake, fake, 0, fake, fake, st3(st), fake, st3(st),
+                                RENI_LOSS_MSE, 0.f, 0.f, fake, fake, fake, fake, 1e-3f, .9f, .999f, 1e-8f, 1, 1.f, &st, terms, fake, fake,
+                                ws, 16, NULL), RENI_EWORKSPACE); }
   EXPECT(reni_backward(p, 2, 256, fake, fake, 0, fake, NULL, 3, fake, fake, ws, 16, NULL), RENI_EINVAL);
   EXPECT(reni_backward(p, 2, 256, fake, fake, 0, fake, fake, 3, fake, fake, ws, 16, NULL), RENI_EWORKSPACE);
   /* a concat plan through the FiLM entry points, and the other way round */

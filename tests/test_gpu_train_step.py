@@ -1,0 +1,76 @@
+"""reni_train_step_rows (the fused training step: fwd + loss + bwd, Adam over decoder + latent table, the next batch's prologue) against
+the two calls it replaces (reni_forward_loss_backward_rows + reni_adam_step2): the SAME kernels on the same data in another order,
+so every buffer must come out bit-equal -- parameters, latents, both Adam moments, the loss terms of every step."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(dtype, H, L, N, fused, seed=0):
+    from reni_amd.engine import TrainEngine
+    from reni_amd.models import RENIAutoDecoder
+    torch.manual_seed(seed)
+    m = RENIAutoDecoder(N, 9, "SO2", H, L, 3, True, "tanh", 30.0, 30.0, False)
+    m.set_compute_dtype(dtype).to("cuda:0")
+    return m, TrainEngine(m, lr=1e-3, fused_step=fused)
+
+
+def _data(N, W, dev):
+    from reni_amd.utils import get_directions, get_sineweight
+    D, S = get_directions(W).to(dev), get_sineweight(W).to(dev)
+    T = torch.stack([torch.rand(D.shape[1], 3, generator=torch.Generator().manual_seed(300 + i)) * 2 - 1 for i in range(N)]).to(dev)
+    return D, S, T
+
+
+def _state(m, e):
+    return [t.detach().clone() for t in (m._flat_params(), m.Z.data, e.m_dec, e.v_dec, e.m_lat, e.v_lat)]
+
+
+@pytest.mark.parametrize("dtype,H,L,W,B,announce", [
+    ("bf16", 128, 5, 256, 8, True),    # persistent kernels, 2 048 tiles = 8 per workgroup: forked (Adam + prologue beside k_reni_dw1)
+    ("bf16", 128, 5, 64, 4, True),     # persistent kernels, 64 tiles: one stream
+    ("bf16", 128, 3, 64, 4, False),    # nothing announced: every call runs its own prologue
+    ("f32", 64, 3, 32, 4, True),       # generic kernels: the same work in sequence
+    ("bf16", 256, 2, 32, 2, True),     # H = 256 (fragment stream)
+])
+def test_fused_step_is_bit_equal_to_the_two_calls(dtype, H, L, W, B, announce):
+    dev = torch.device("cuda:0")
+    N = 3 * B
+    D, S, T = _data(N, W, dev)
+    batches = [torch.arange(B, device=dev) + o for o in (0, B, 2 * B, B, 0, 2 * B)]
+    batches[3] = torch.tensor(list(range(N - 1, N - 1 - B, -1)), device=dev)   # (not a contiguous run of rows)
+    res = {}
+    for fused in (False, True):
+        m, e = _engine(dtype, H, L, N, fused)
+        terms = []
+        for k, idx in enumerate(batches):
+            nxt = batches[k + 1] if (announce and k + 1 < len(batches)) else None
+            terms.append(e.step(idx, T[idx], S, D, next_idx=nxt).clone())
+        torch.cuda.synchronize()
+        res[fused] = (torch.stack(terms), _state(m, e), e)
+    assert res[True][2]._stage is not None and res[False][2]._stage is None      # the fused path really ran
+    assert torch.equal(res[False][0], res[True][0]), (res[False][0], res[True][0])
+    for a, b, name in zip(res[False][1], res[True][1], ("params", "Z", "m_dec", "v_dec", "m_lat", "v_lat")):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+
+
+def test_a_batch_other_than_the_staged_one_poisons_the_step():
+    """The library compares the batch a staged prologue was run for with the batch the next call brings, on the device: a mismatch
+    the host-side identity check cannot see (same tensor, other contents) yields NaN, not a silently wrong step."""
+    dev = torch.device("cuda:0")
+    B, N = 4, 12
+    D, S, T = _data(N, 64, dev)
+    m, e = _engine("bf16", 128, 5, N, True)
+    idx = torch.arange(B, device=dev)
+    nxt = torch.arange(B, device=dev) + B
+    e.step(idx, T[idx], S, D, next_idx=nxt)
+    nxt[1] = 11                                  # the announced batch is changed in place behind the engine's back
+    t = e.step(nxt, T[nxt], S, D)
+    assert bool(torch.isnan(t[0]))
+    # announcing nothing, or another tensor: the call simply runs its own prologue
+    m2, e2 = _engine("bf16", 128, 5, N, True)
+    e2.step(idx, T[idx], S, D, next_idx=nxt)
+    other = torch.tensor([2, 5, 7, 9], device=dev)
+    t2 = e2.step(other, T[other], S, D)
+    assert bool(torch.isfinite(t2).all())
