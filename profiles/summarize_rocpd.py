@@ -1,5 +1,5 @@
 """Summarise a rocprofv3 rocpd database (kernel trace) into a per-kernel stats table (markdown).
-usage: python profiles/summarize_rocpd.py <results.db> [out.md [K]]"""
+usage: python profiles/summarize_rocpd.py <results.db> [out.md [K [W]]]"""
 import sqlite3
 import sys
 
@@ -15,17 +15,18 @@ def main():
     out = ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
     for n, cnt, s, a, mn, mx in rows:
         out.append(f"| `{n[:110]}` | {cnt} | {s/1e6:.3f} | {a/1e3:.1f} | {mn/1e3:.1f} | {mx/1e3:.1f} | {100*s/tot:.1f} |")
-    # the default bench command runs its sub-records first: the headline's K timed steps are the LAST K launches of the training
-    # kernel in the process (argument 3 = K) -- their average is what the bench line's kernel_avg_ms must agree with
+    # the default bench command: the headline's W warm-up + K timed steps come FIRST (arguments 3, 4 = K, W), the sub-records behind
+    # them, the same W + K steps once more at the end (`sustained`).  The average of launches W .. W+K-1 of the training kernel is what
+    # the bench line's roofline.kernel_avg_ms must agree with; the last K launches are the sustained window.
     if len(sys.argv) > 3:
         k = int(sys.argv[3])
-        last = c.execute(f"select end-start from kernels where {name_col} like '%k_reni_train_bf16<128, true, false, false, true>%' "
-                         f"order by start desc limit {k}").fetchall()
-        if last:
-            d = [r[0] for r in last]
-            out.append("")
-            out.append(f"headline window: the last {len(d)} launches of `k_reni_train_bf16<128, true, false, false, true>`: "
-                       f"avg {sum(d)/len(d)/1e3:.1f} us, min {min(d)/1e3:.1f} us, max {max(d)/1e3:.1f} us")
+        w = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+        key = "k_reni_train_bf16<128, true, false, false, true>"
+        allr = [r[0] for r in c.execute(f"select end-start from kernels where {name_col} like '%{key}%' order by start").fetchall()]
+        for title, d in (("headline window (launches %d..%d)" % (w, w + k - 1), allr[w:w + k]), ("sustained window (the last %d launches)" % k, allr[-k:])):
+            if d:
+                out.append("")
+                out.append(f"{title} of `{key}`: avg {sum(d)/len(d)/1e3:.1f} us, min {min(d)/1e3:.1f} us, max {max(d)/1e3:.1f} us")
     text = "\n".join(out)
     print(text)
     if len(sys.argv) > 2:

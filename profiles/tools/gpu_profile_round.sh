@@ -21,14 +21,14 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VM
 done
 python3 profiles/make_pmc_traffic.py $O/pmc_counters.md $O/pmc_instruction_mix.md > $O/pmc_traffic.json 2>> $O/bench.err
 cp $O/pmc_traffic.json profiles/pmc_traffic.json   # (so that the bench lines below carry the traffic of THIS source state)
-for c in c2 c4 c5 film; do
-  X="--no-cpu-baseline"; [ $c = c2 ] && X=""
-  python bench.py --config $c $X > $O/bench_$c.json 2>> $O/bench.err; cut -c1-200 $O/bench_$c.json
+for c in c2 c4 c5 film c2_curric c2_h256; do
+  X="--config $c --no-cpu-baseline"; [ $c = c2 ] && X="--steps 20 --warmup 5"   # (c2: exactly the driver's command)
+  python bench.py $X > $O/bench_$c.json 2>> $O/bench.err; cut -c1-200 $O/bench_$c.json
 done
 for c in c2 c4 c5 film; do
-  # c2: the DEFAULT command (sub-records first, then the headline's 5 + 20 steps): the summary's last line is the average of the
-  # headline's 20 timed launches
-  X="--config $c --steps 10 --warmup 2 --no-also"; K=""; [ $c = c2 ] && { X="--steps 20 --warmup 5"; K=20; }
+  # c2: the DEFAULT command as the driver runs it (the headline's 5 + 20 steps first, the sub-records, the same steps again): the
+  # summary's last two lines are the averages of the headline's and of the sustained window's 20 timed launches
+  X="--config $c --steps 10 --warmup 2 --no-also"; K=""; [ $c = c2 ] && { X="--steps 20 --warmup 5"; K="20 5"; }
   rocprofv3 --kernel-trace --stats -d $O/kt_$c -o k -- python3 bench.py $X --no-cpu-baseline > $O/kt_$c.log 2>&1
   python3 profiles/summarize_rocpd.py $O/kt_$c/k_results.db $O/kernel_stats_$c.md $K > /dev/null 2>&1 || ls -R $O/kt_$c | head
   { [ $c = c2 ] || [ $c = film ]; } && python3 profiles/timeline_rocpd.py $O/kt_$c/k_results.db > $O/step_timeline_$c.txt 2>/dev/null

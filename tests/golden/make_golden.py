@@ -11,6 +11,8 @@ import os
 import sys
 import types
 
+sys.dont_write_bytecode = True  # importing the reference must not write __pycache__ under /root/reference (read-only by rule)
+
 import numpy as np
 import torch
 
