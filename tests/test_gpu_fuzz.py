@@ -56,6 +56,8 @@ def test_fuzz_against_oracle(c):
         errs += [O.rel_l2(rb["grads"][k].float().numpy(), v.numpy()) for k, v in ref["grads"].items() if float(v.abs().max()) > 0]
         return max(TOL["bf16"]["grad"], 1.5 * max(errs))
 
+    BF16_CAP = 0.15  # a derived bound above this asserts nothing: such a case is checked through the fp32 kernels instead
+
     if c["dtype"] == "bf16" and B * P < 8:
         # A gradient from fewer than eight samples through up to eight sine layers is ill-conditioned: on the one-sample
         # case of a 600-case run fp32 itself kept 3.5 digits (3e-4) and bf16 none (profiles/tools/gpu_fuzz_one.py).  A bf16 gradient
@@ -70,6 +72,9 @@ def test_fuzz_against_oracle(c):
         ref = O.film_fwd_loss_bwd(spec, params, Z, D.expand(B, P, 3), T, S)
         if own_bf16:
             tol["grad"] = bf16_bound(ref, lambda: O.film_fwd_loss_bwd(spec, params, Z, D.expand(B, P, 3), T, S))
+            if tol["grad"] > BF16_CAP:   # ill-conditioned for ANY bf16 arithmetic: the shape is checked at fp32 precision
+                c = dict(c, dtype="f32")
+                tol = dict(loss=5e-6, grad=1e-3)
         m = RENIAutoDecoderFiLM(B, nd, c["eq"], H, L + 1, 12, 1, 3, c["act"], c["frozen"])
         m.load_state_dict({"model." + k: v for k, v in params.items()}, strict=False)
         m.set_compute_dtype(c["dtype"]).to(dev)
@@ -89,6 +94,9 @@ def test_fuzz_against_oracle(c):
         ref = O.fwd_loss_bwd(spec, params, Z, D.expand(B, P, 3), T, S.expand(B, P, 3))
         if own_bf16:
             tol["grad"] = bf16_bound(ref, lambda: O.fwd_loss_bwd(spec, params, Z, D.expand(B, P, 3), T, S.expand(B, P, 3)))
+            if tol["grad"] > BF16_CAP:   # ill-conditioned for ANY bf16 arithmetic: the shape is checked at fp32 precision
+                c = dict(c, dtype="f32")
+                tol = dict(loss=5e-6, grad=1e-3)
         plan = make_plan(spec, c["dtype"])
         fp = flat_params(spec, params).to(dev)
         lt, dZ, dp, out = plan.forward_loss_backward(Z.to(dev), D.to(dev), fp, T.to(dev), S.to(dev), need_dw=not c["frozen"], want_out=True)

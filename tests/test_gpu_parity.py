@@ -175,7 +175,8 @@ def test_cosine_loss_on_the_persistent_kernels(dev, L):
                     # reference's own arithmetic gives on this problem when its linear layers run in bf16 (autocast), x 1.5.
                     with torch.autocast("cpu", dtype=torch.bfloat16):
                         rb = O.fwd_loss_bwd(spec, params, Z, D.expand(B, P, 3), T, Wm.expand(B, P, 3), "test", 1e-3, 1e-1)
-                    t = max(t, 1.5 * O.rel_l2(rb["grads"][k].float().numpy(), ref["grads"][k].numpy()))
+                    # (capped: where the reference's own bf16 run is off by more than 10 %, 1.5 x that asserts nothing -- ADVICE r03)
+                    t = min(max(t, 1.5 * O.rel_l2(rb["grads"][k].float().numpy(), ref["grads"][k].numpy())), 0.15)
                 e = O.rel_l2(gp[k].numpy(), ref["grads"][k].numpy())
                 assert e <= t, (k, e, t)
 
