@@ -505,3 +505,36 @@ def test_fit_decoder_from_exr_files_on_disk(dev, tmp_path):
     lin = mod.dataset.unnormalise(img)                                     # device epilogue (reni_unnormalise_srgb)
     view = sRGB(lin)
     assert lin.is_cuda and bool(torch.isfinite(lin).all()) and float(view.min()) >= 0 and float(view.max()) <= 1
+
+
+def test_fused_epilogue_shapes_of_the_persistent_training_path(dev):
+    """k_tail_a / k_tail_b (round 4: the per-image epilogue of the persistent training path in two launches) at the shapes that stress
+    their bookkeeping: ONE image spread over all 256 workgroups (256 image runs in its list), need_dz = False (one block per image, no
+    m columns, no dZ blocks), and run-to-run bit-equality of everything they produce."""
+    spec = O.DecoderSpec(36, "SO2", 128, 5, 3, True, "tanh")
+    params, Z, D, W, T = random_problem(spec, 1, 0, seed=77, grid_w=256)   # 1 image x 32 768 directions = 256 tiles
+    plan = make_plan(spec, "bf16")
+    fp = flat_params(spec, params).to(dev)
+    args = (Z.to(dev), D.to(dev), fp, T.to(dev), W.to(dev))
+    lt, dZ, dp, _ = plan.forward_loss_backward(*args)
+    lt2, dZ2, dp2, _ = plan.forward_loss_backward(*args)
+    assert torch.equal(lt, lt2) and torch.equal(dZ, dZ2) and torch.equal(dp, dp2)
+    ref = O.fwd_loss_bwd(spec, params, Z, D.expand(1, -1, 3), T, W.expand(1, -1, 3))
+    assert abs(float(lt[0]) - ref["loss_terms"][0]) <= 3e-3 * abs(ref["loss_terms"][0])
+    assert O.rel_l2(dZ.cpu().numpy(), ref["dZ"].numpy()) <= 3e-2
+    gp = unflatten(spec, dp.cpu())
+    for k in gp:
+        if gp[k].numel() > 3:
+            assert O.rel_l2(gp[k].numpy(), ref["grads"][k].numpy()) <= 3e-2, k
+    # without the latent gradient: the same decoder gradient and loss, bit for bit
+    lt3, dZ3, dp3, _ = plan.forward_loss_backward(*args, need_dz=False)
+    assert dZ3 is None and torch.equal(lt3, lt) and torch.equal(dp3, dp)
+    # three images whose tile ranges cut through workgroups (3 x 40 tiles over 120 workgroups, then over fewer: 3 x 300 tiles / 256)
+    for w in (80, 160):
+        params, Z, D, W, T = random_problem(spec, 3, 0, seed=78, grid_w=w)
+        fp = flat_params(spec, params).to(dev)
+        lt, dZ, dp, _ = plan.forward_loss_backward(Z.to(dev), D.to(dev), fp, T.to(dev), W.to(dev))
+        ref = O.fwd_loss_bwd(spec, params, Z, D.expand(3, -1, 3), T, W.expand(3, -1, 3))
+        assert abs(float(lt[0]) - ref["loss_terms"][0]) <= 3e-3 * abs(ref["loss_terms"][0])
+        assert O.rel_l2(dZ.cpu().numpy(), ref["dZ"].numpy()) <= 3e-2
+        assert O.rel_l2(unflatten(spec, dp.cpu())["net.0.linear.weight"].numpy(), ref["grads"]["net.0.linear.weight"].numpy()) <= 3e-2
