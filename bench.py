@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=None,
                     help="images per GPU per step (c2: 64, <= 615/8 so that 8 ranks can own them; c4: 21; c5: 4)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32"], help="c2 / c4: bf16, c5: f32")
+    ap.add_argument("--res", default=None, help="c2 only: HxW of the equirect grid (e.g. 16x32: one stage of the curriculum on its own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-also", action="store_true", help="skip the c4 / c5 / film sub-records of the default (c2) line")
@@ -474,7 +475,8 @@ def main():
     elif cfg == "c2_h256":
         head = run_config("c2", args, rank, world, dev, batch=args.batch, hidden=256, defer=True)
     else:
-        head = run_config(cfg, args, rank, world, dev, batch=args.batch, defer=True)  # set-up only
+        res = tuple(int(x) for x in args.res.split("x")) if (args.res and cfg == "c2") else None
+        head = run_config(cfg, args, rank, world, dev, batch=args.batch, res=res, defer=True)  # set-up only
     # THE headline: W warm-up + K timed steps, first, identically with and without the sub-records
     rec = head()
     if cfg == "c2" and not args.no_also:
