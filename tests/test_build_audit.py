@@ -73,8 +73,9 @@ def test_training_kernel_agprs_only_in_hand_written_asm():
     assert mfma > 20 and touching == 0 and scratch == 0
     # the FiLM instances (reni_tu_train_film.hip): same rules
     text = _isa("train_film")
-    mfma, touching, outside, scratch = _train_kernel_counts(text, "_ZN4reni17k_reni_train_bf16ILi128ELb1ELb0ELb1ELb0EEE")
-    assert mfma > 100 and touching >= 512 and outside == 0 and scratch == 0
+    for inst in ("_ZN4reni17k_reni_train_bf16ILi128ELb1ELb0ELb1ELb0EEE", "_ZN4reni17k_reni_train_bf16ILi128ELb1ELb0ELb1ELb1EEE"):  # generic, SPEC
+        mfma, touching, outside, scratch = _train_kernel_counts(text, inst)
+        assert mfma > 100 and touching >= 512 and outside == 0 and scratch == 0
     mfma, touching, outside, scratch = _train_kernel_counts(text, "_ZN4reni17k_reni_train_bf16ILi128ELb0ELb1ELb1ELb0EEE")
     assert mfma > 20 and touching == 0 and scratch == 0
 
