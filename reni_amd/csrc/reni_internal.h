@@ -131,7 +131,7 @@ struct TailArgs {
   int eq, nd, F_in, H, B;
 };
 
-// FiLM per-image glue (k_film_map_fwd / k_film_map_bwd / k_film_wgrad / k_film_w0grad): the mapping network
+// FiLM per-image glue (k_film_minput / k_film_linear / k_film_fold; k_film_dout / k_film_linear_t / k_film_grads): the mapping network
 // (src/models/RENI.py:482-505), freq = 15 f + 30, and the first FiLM layer folded into the per-image affine map
 constexpr int MAX_MAP_LAYERS = 8;
 struct FilmGlueArgs {
