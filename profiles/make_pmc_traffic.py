@@ -22,7 +22,7 @@ for path in sys.argv[1:]:
 names = {"k_reni_train_bf16<128, true, false, false, true>": "k_reni_train_bf16<128,true>",   # (the SPEC instance: what config 2 runs)
          "k_reni_train_bf16<128, false, false, false, false>": "k_reni_train_bf16<128,false>",
          "k_reni_train_bf16<128, false, true, false, false>": "k_reni_train_bf16<128,false,true>",
-         "k_reni_train_bf16<128, true, false, true, false>": "k_reni_train_bf16<128,true,false,true>",
+         "k_reni_train_bf16<128, true, false, true, true>": "k_reni_train_bf16<128,true,false,true>",   # (FiLM: its SPEC instance)
          "k_reni_main<reni::PolF32, 128, 0, false>": "k_reni_main<f32,H=128,FWD>"}
 sha = kernel_src_sha()
 out = {}
