@@ -537,4 +537,7 @@ def test_fused_epilogue_shapes_of_the_persistent_training_path(dev):
         ref = O.fwd_loss_bwd(spec, params, Z, D.expand(3, -1, 3), T, W.expand(3, -1, 3))
         assert abs(float(lt[0]) - ref["loss_terms"][0]) <= 3e-3 * abs(ref["loss_terms"][0])
         assert O.rel_l2(dZ.cpu().numpy(), ref["dZ"].numpy()) <= 3e-2
-        assert O.rel_l2(unflatten(spec, dp.cpu())["net.0.linear.weight"].numpy(), ref["grads"]["net.0.linear.weight"].numpy()) <= 3e-2
+        gp = unflatten(spec, dp.cpu())
+        for k in gp:   # (every layer: below eight tiles per workgroup the partial reduction of layers >= 2 rides in k_tail_a's launch,
+            if gp[k].numel() > 3:   # and 300 tiles run on 150 workgroups of two -- the balanced count -- not on 256 of one or two)
+                assert O.rel_l2(gp[k].numpy(), ref["grads"][k].numpy()) <= 3e-2, (w, k)
