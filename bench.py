@@ -66,6 +66,7 @@ def parse():
                     help="images per GPU per step (c2: 64, <= 615/8 so that 8 ranks can own them; c4: 21; c5: 4)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32"], help="c2 / c4: bf16, c5: f32")
     ap.add_argument("--res", default=None, help="c2 only: HxW of the equirect grid (e.g. 16x32: one stage of the curriculum on its own)")
+    ap.add_argument("--dense", action="store_true", help="c4: RENI_WEIGHT_SPARSE off (every tile, and the statistics pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-also", action="store_true", help="skip the c4 / c5 / film sub-records of the default (c2) line")
@@ -231,7 +232,7 @@ def mask3(sidelen):
     return mask_from_array(sidelen, src)
 
 
-def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None, defer=False, res=None, hidden=128, eq="SO2"):
+def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None, defer=False, res=None, hidden=128, eq="SO2", dense=False):
     """One bench configuration in this process: build the model / engine, warm up, time `steps` steps between barriers.
     Returns the record (value, ms_per_step, roofline ...) on every rank; timing is the MAX over ranks.
     res = (height, width) of the c2 step's images (the multi-resolution curriculum), hidden = the SIREN's width."""
@@ -294,7 +295,18 @@ def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None,
             # the notebook's inpainting mask (examples.ipynb cell 4: data/Masks/Mask-3.png, rows 20-92 x columns 81-164 of 128 x 256
             # kept = 18.8 % of the pixels), multiplied into the sine weight (RENI_module.py:92-94)
             weight = sineweight * mask3(W_IMG).to(dev)
-            eng = TrainEngine(model, lr=1e-1, loss_kind="test", alpha=1e-7, beta=1e-4)
+            # sparse_weight: what RENI.training_step passes whenever a mask is configured (lightning_module.py) -- RENI_WEIGHT_SPARSE:
+            # tiles whose 128 pixels all have zero weight, and the statistics pass of images whose pixel-0 weight is zero, cannot
+            # change the result and are left out (on the device, from the weight, every call).  dense=True: the flag off.
+            eng = TrainEngine(model, lr=1e-1, loss_kind="test", alpha=1e-7, beta=1e-4, sparse_weight=not dense)
+            wz = (weight.reshape(-1, 3) != 0).any(1)                                  # (host-side bookkeeping for the record only)
+            cos_live = bool(wz[0])
+            tiles = torch.nn.functional.pad(wz, (0, (-wz.numel()) % 128)).view(-1, 128).any(1)
+            sparsity = {"flag": "RENI_WEIGHT_SPARSE" if not dense else "off",
+                        "pixels_with_weight": float(wz.float().mean()), "tiles_with_weight": float(tiles.float().mean()),
+                        "cosine_term_live": cos_live,
+                        "tiles_visited": 1.0 if (dense or cos_live) else float(tiles.float().mean()),
+                        "statistics_pass": "run" if (dense or cos_live) else "skipped on the device (pixel-0 weight is zero: the term is a constant)"}
 
         def step(s):
             """B consecutive owned images; targets are the reference's permute+view of [B,3,H,W]
@@ -313,7 +325,8 @@ def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None,
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    shape = {"cfg": cfg, "B": B, "P": P, "ND": ND, "hidden": hidden, "res": (H_IMG, W_IMG), "eq": eq}
+    shape = {"cfg": cfg, "B": B, "P": P, "ND": ND, "hidden": hidden, "res": (H_IMG, W_IMG), "eq": eq,
+             "sparsity": sparsity if cfg == "c4" else None}
     try:
         paths = model._plan().path_info(B, P, need_dw=cfg in ("c2", "film"))
     except Exception as e:  # noqa: BLE001  (diagnostics only)
@@ -379,14 +392,17 @@ def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, 
         kernel = "k_reni_train_bf16<128,false>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD>"
         workload = ("BASELINE config 4: test-time latent optimisation, 21 held-out maps, 128x256 equirect, ND=36, 5x128 SIREN, "
                     "frozen decoder, the reference's Mask-3 (18.8 % kept), RENITestLoss(1e-7,1e-4) with the cosine term, per-image "
-                    "latent Adam lr 0.1; full step (statistics pass + latent fwd/bwd + Adam)")
+                    "latent Adam lr 0.1; full step (statistics pass where the cosine term is live + latent fwd/bwd + Adam)")
     else:
         flop = FLOP_FWD_ND49
         kernel = "k_reni_main<f32,H=128,FWD>" if dtype == "f32" else "k_reni_train_bf16<128,false,true>"
         workload = f"BASELINE config 5: inference, 512x1024 directions, ND=49, 5x128 SIREN, {shape['eq']}, 4 images per step"
     # achieved = the algorithmic FLOPs of the timed steps / the dominant kernel's total run time in them (HIP events on its stream):
     # per launch this is flop x samples per launch / average launch duration, also when a step is several launches (H = 256: chunks)
-    achieved = B * P * steps * flop / (max(kern_ms, 1e-9) * 1e-3) / 1e12
+    # (c4 with RENI_WEIGHT_SPARSE: only the tiles the kernel visits are counted -- `value` counts every direction of the images, as the
+    # reference evaluates them all for the same result)
+    visited = shape["sparsity"]["tiles_visited"] if shape.get("sparsity") else 1.0
+    achieved = visited * B * P * steps * flop / (max(kern_ms, 1e-9) * 1e-3) / 1e12
     pmc = pmc_record(kernel)
     roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
             "frac": achieved / PEAK_TFLOPS[dtype], "traffic": pmc.get("hbm_bytes_per_launch"), "kernel": kernel,
@@ -404,6 +420,8 @@ def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, 
            "config": {"workload": workload, "images_per_gpu_per_step": B, "global_batch_images": world * B,
                       "directions_per_image": P, "parallelism": f"dp{world}", "result_check": check, "paths": paths},
            "roofline": roof}
+    if shape.get("sparsity"):
+        rec["config"]["weight_sparsity"] = shape["sparsity"]
     if world > 1 and cfg in ("c2", "film"):
         rec["exchange"] = {"kind": "reni_allreduce_grads (C ABI, librccl)" if args.comm == "capi" else
                            f"torch.distributed all_reduce ({torch.distributed.get_backend()})",
@@ -429,16 +447,20 @@ def sub_record(name, args, rank, world, dev):
     elif name.startswith("c2_curric_"):   # the reference's real schedule: B = 100 at 16x32 / 32x64 / 64x128
         h, w = (int(x) for x in name[len("c2_curric_"):].split("x"))
         r = run_config("c2", args, rank, world, dev, batch=100, res=(h, w), **kw)
+    elif name == "c4_dense":  # config 4 with RENI_WEIGHT_SPARSE off: every tile, and the statistics pass (the figure of rounds 1-3)
+        r = run_config("c4", args, rank, world, dev, dense=True, **kw)
     elif name == "c2_h256":   # the width of the reference's shipped configs (configs/default.py:13)
         r = run_config("c2", args, rank, world, dev, hidden=256, **kw)
     else:
         r = run_config(name, args, rank, world, dev, **kw)
     out = {"metric": METRIC_FWD if name == "c5" else METRIC_TRAIN.replace("128x256", "%dx%d" % tuple(int(x) for x in name[10:].split("x")))
            if name.startswith("c2_curric_") else METRIC_TRAIN,
-           "value": r["value"] / (world if name in ("c4", "c5") else 1), "unit": "samples/s",
+           "value": r["value"] / (world if name in ("c4", "c4_dense", "c5") else 1), "unit": "samples/s",
            "ms_per_step": r["ms_per_step"], "steps": r["steps"], "launches_per_step": r["launches_per_step"],
            "dtype": r["dtype"], "workload": r["config"]["workload"],
            "images_per_gpu_per_step": r["config"]["images_per_gpu_per_step"], "paths": r["config"]["paths"], "roofline": r["roofline"]}
+    if "weight_sparsity" in r["config"]:
+        out["weight_sparsity"] = r["config"]["weight_sparsity"]
     if name == "c5":  # SURVEY 8(d) C5 names both invariances: the SO3 model through the same kernel
         r3 = run_config("c5", args, rank, world, dev, eq="SO3", **kw)
         out["so3"] = {"value": r3["value"] / world, "ms_per_step": r3["ms_per_step"], "frac": r3["roofline"]["frac"],
@@ -476,7 +498,7 @@ def main():
         head = run_config("c2", args, rank, world, dev, batch=args.batch, hidden=256, defer=True)
     else:
         res = tuple(int(x) for x in args.res.split("x")) if (args.res and cfg == "c2") else None
-        head = run_config(cfg, args, rank, world, dev, batch=args.batch, res=res, defer=True)  # set-up only
+        head = run_config(cfg, args, rank, world, dev, batch=args.batch, res=res, defer=True, dense=args.dense)  # set-up only
     # THE headline: W warm-up + K timed steps, first, identically with and without the sub-records
     rec = head()
     if cfg == "c2" and not args.no_also:
@@ -485,7 +507,7 @@ def main():
         # configurations whose ranks are independent (c4, c5: rank 0's own replica).
         also = {}
         user_dtype = args.dtype
-        names = (("c4", "c5", "film", "c2_b100") + tuple(f"c2_curric_{h}x{w}" for h, w in CURRIC) + ("c2_h256",)) if world == 1 else ("c4", "c5")
+        names = (("c4", "c4_dense", "c5", "film", "c2_b100") + tuple(f"c2_curric_{h}x{w}" for h, w in CURRIC) + ("c2_h256",)) if world == 1 else ("c4", "c5")
         for c in names:
             args.dtype = None
             try:

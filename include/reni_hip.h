@@ -61,6 +61,12 @@ extern "C" {
 /* flags */
 #define RENI_NEED_DW 1u /* produce decoder gradients (dparams)                      */
 #define RENI_NEED_DZ 2u /* produce latent gradients (dZ)                            */
+/* The loss weight is zero over whole regions (RENI_module.py:92-94: sineweight * mask, the notebook's inpainting masks): the library
+ * may leave out work that cannot change the result -- 128-pixel tiles whose weights are all zero, and the statistics pass of
+ * RENITestLoss's cosine term for images whose pixel-0 weight is zero (loss_functions.py:25-32 multiplies the term by that weight).
+ * The regions are found on the device from `weight` in every call; results are the dense ones (the skipped terms are exact zeros).
+ * Honoured by the frozen-decoder calls on the persistent bf16 kernels (no RENI_NEED_DW), ignored elsewhere. */
+#define RENI_WEIGHT_SPARSE 4u
 
 typedef struct reni_plan reni_plan;
 
@@ -199,8 +205,8 @@ int reni_film_backward(const reni_plan* plan, int64_t B, int64_t P, const float*
                        uint32_t flags, float* dA, float* dfilm, float* dparams, void* ws, size_t ws_bytes,
                        void* stream);
 
-/* FiLM, whole model: the per-image glue of the three calls above runs in HIP too (k_film_map_fwd / _bwd,
- * k_film_wgrad, k_film_w0grad), so these take the latent codes and the mapping network's parameters and return
+/* FiLM, whole model: the per-image glue of the three calls above runs in HIP too (k_film_minput / _linear / _fold,
+ * k_film_dout / _linear_t / _grads), so these take the latent codes and the mapping network's parameters and return
  * their gradients -- the drop-in for RENI*FiLM.forward (RENI.py:628-676) + criterion + loss.backward().
  *   map_params / dmap_params : mapping_network.network.{0,2,...}.{weight [N_i,K_i], bias [N_i]} flat, in state-dict
  *                              order (RENI.py:482-496); reni_film_map_param_count() elements;

@@ -70,6 +70,10 @@ struct MainArgs {
   int* prun_image;
   int pkmax;
   int nwg_main;  // grid of the training kernel (k_reni_dw1 walks each workgroup's range backwards: most recent first)
+  // RENI_WEIGHT_SPARSE (frozen-decoder and statistics instances of the persistent kernel): the tiles to visit, ascending, and their
+  // number -- built on the device from the loss weight by k_tile_flags / k_tile_compact.  NULL: every tile.
+  const int* tlist;
+  const int* tcount;
 };
 
 // sets reni_last_error()'s thread-local message and returns `code` (defined next to the C ABI, reni_capi.inc)

@@ -176,7 +176,8 @@ class RENI(_Base):
                 loss, mse_loss, kld_loss = self.criterion.fused(self.model, Z, directions, imgs, sineweight, mu, log_var)
                 log_dict = {"loss": loss, "mse_loss": mse_loss, "kld_loss": kld_loss}
         elif self.task == "FIT_LATENT":
-            loss, mse_loss, prior_loss, cosine_loss = self.criterion.fused(self.model, Z, directions, imgs, sineweight)
+            loss, mse_loss, prior_loss, cosine_loss = self.criterion.fused(self.model, Z, directions, imgs, sineweight,
+                                                                           sparse_weight=self.mask is not None)
             log_dict = {"loss": loss, "mse_loss": mse_loss, "prior_loss": prior_loss, "cosine_loss": cosine_loss}
         return log_dict
 

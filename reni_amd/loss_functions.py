@@ -75,8 +75,9 @@ class RENITestLoss(object):
         cosine_loss = self.beta * WeightedCosineSimilarity(inputs, targets, sineweight)
         return mse_loss + prior_loss + cosine_loss, mse_loss, prior_loss, cosine_loss
 
-    def fused(self, model, Z, directions, targets, sineweight):
-        t = model.fused_loss(Z, directions, targets, sineweight, "test", self.alpha, self.beta)
+    def fused(self, model, Z, directions, targets, sineweight, sparse_weight=False):
+        """sparse_weight: the weight carries an inpainting mask (RENI_module.py:92-94) -- see ops.Plan.forward_loss_backward."""
+        t = model.fused_loss(Z, directions, targets, sineweight, "test", self.alpha, self.beta, sparse_weight=sparse_weight)
         return t[0], t[1], t[2], t[3]
 
 

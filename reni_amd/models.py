@@ -128,13 +128,13 @@ class _FusedLossFn(torch.autograd.Function):
     of ``loss`` produced in the same fused kernel launch; backward only rescales them."""
 
     @staticmethod
-    def forward(ctx, model, loss_kind, alpha, beta, target, weight, Z, D, *params):
+    def forward(ctx, model, loss_kind, alpha, beta, sparse_weight, target, weight, Z, D, *params):
         flat = model._flat_params()
         need_dw = any(p.requires_grad for p in params)
         need_dz = Z.requires_grad
         terms, dZ, dparams, _ = model._plan().forward_loss_backward(
             Z, D, flat, target, weight, loss_kind=loss_kind, alpha=alpha, beta=beta,
-            need_dw=need_dw, need_dz=need_dz)
+            need_dw=need_dw, need_dz=need_dz, sparse_weight=sparse_weight)
         ctx.model = model
         ctx.n_params = len(params)
         ctx.need_dw, ctx.need_dz = need_dw, need_dz
@@ -150,7 +150,7 @@ class _FusedLossFn(torch.autograd.Function):
             grads = ctx.model._split_flat(ctx.dparams * s)
         else:
             grads = [None] * ctx.n_params
-        return (None, None, None, None, None, None, dZ, None, *grads)
+        return (None, None, None, None, None, None, None, dZ, None, *grads)
 
 
 # --------------------------------------------------------------------------------------------
@@ -262,11 +262,11 @@ class _RENIConcatBase(nn.Module):
             raise AssertionError("latent batch and directions batch differ")  # RENI.py:213,220
         return _DecodeFn.apply(self, Z, directions, *self._net_params())
 
-    def fused_loss(self, Z, directions, target, weight, loss_kind="mse", alpha=0.0, beta=0.0):
+    def fused_loss(self, Z, directions, target, weight, loss_kind="mse", alpha=0.0, beta=0.0, sparse_weight=False):
         """criterion(model(Z, D), target, weight[, Z]) as ONE fused forward+loss+backward launch.
         Returns the 4-vector (loss, mse, prior, cosine); ``.backward()`` on element 0 delivers the
         gradients the kernel already computed."""
-        return _FusedLossFn.apply(self, loss_kind, float(alpha), float(beta), target, weight, Z, directions,
+        return _FusedLossFn.apply(self, loss_kind, float(alpha), float(beta), bool(sparse_weight), target, weight, Z, directions,
                                   *self._net_params())
 
     # ---- checkpoint remap (RENI.py:190-203 / 347-360) -----------------------------------------

@@ -134,12 +134,14 @@ class Plan:
         return out
 
     def forward_loss_backward(self, Z, D, params, target, weight, loss_kind="mse", alpha=0.0, beta=0.0,
-                              need_dw=True, need_dz=True, want_out=False, idx=None):
+                              need_dw=True, need_dz=True, want_out=False, idx=None, sparse_weight=False):
         """target / weight: any strided [B,P,3] views (stride 0 broadcasts); returns
         (loss_terms[4] device tensor, dZ or None, dparams or None, out or None).
         idx (int64 device tensor [B]): Z is a latent TABLE and image b uses row idx[b] (gathered inside the prologue
         kernel: reni_forward_loss_backward_rows); dZ stays [B,ND,3] in batch order.  An index outside the table makes the
-        call's loss and gradients NaN (no out-of-bounds read, no host synchronisation to check it)."""
+        call's loss and gradients NaN (no out-of-bounds read, no host synchronisation to check it).
+        sparse_weight: the weight is zero over whole regions (an inpainting mask, RENI_module.py:92-94): RENI_WEIGHT_SPARSE --
+        the frozen-decoder persistent kernels then leave out the tiles (and the statistics pass) that cannot change the result."""
         _require_cuda(Z, D, params, target, weight, idx)
         Z = _f32c(Z); params = _f32c(params)
         self._check_zp(Z, params)
@@ -158,7 +160,7 @@ class Plan:
         weight = weight.expand(B, P, 3)
         ts = (ctypes.c_int64 * 3)(*target.stride())
         wst = (ctypes.c_int64 * 3)(*weight.stride())
-        flags = (_lib.NEED_DW if need_dw else 0) | (_lib.NEED_DZ if need_dz else 0)
+        flags = (_lib.NEED_DW if need_dw else 0) | (_lib.NEED_DZ if need_dz else 0) | (_lib.WEIGHT_SPARSE if sparse_weight else 0)
         dev = Z.device
         loss_terms = torch.empty(4, dtype=torch.float32, device=dev)
         dZ = torch.empty(B, self.ndims, 3, dtype=torch.float32, device=dev) if need_dz else None

@@ -396,6 +396,54 @@ def test_c4_full_size_latent_step_bf16(dev):
     assert float(dZ_all.abs().max()) > 0 and torch.isfinite(dZ_all).all()
 
 
+def test_sparse_weight_leaves_out_only_exact_zeros(dev):
+    """RENI_WEIGHT_SPARSE (include/reni_hip.h; RENI.training_step sets it whenever a mask is configured, RENI_module.py:92-94): the
+    frozen-decoder persistent kernels visit only the tiles whose weights are not all zero, and run the cosine term's statistics pass
+    only for images whose pixel-0 weight is not zero (loss_functions.py:25-32 multiplies the term by that weight).  Every record left
+    out is an exact zero in the dense computation: loss terms and latent gradients must be EQUAL, image by image -- here with the
+    notebook's block mask (pixel 0 masked), no mask, an all-zero weight, a single live pixel, and a block mask that keeps pixel 0."""
+    spec = O.DecoderSpec(36, "SO2", 128, 5, 3, True, "tanh")
+    B = 5
+    params, Z, D, W, T = random_problem(spec, B, 0, seed=91, grid_w=128)      # 64 x 128 = 8 192 directions = 64 tiles per image
+    P = D.shape[1]
+    m = torch.zeros(B, 64, 128, 1)
+    m[0, 10:46, 40:83] = 1.0            # Mask-3's block at this resolution (rows 20-92 x columns 81-164 of 128 x 256)
+    m[1] = 1.0                          # no mask
+    m[3, 33, 77] = 1.0                  # one pixel
+    m[4, 10:46, 40:83] = 1.0
+    m[4, 0, 0] = 1.0                    # the block, and pixel 0: the cosine term is live -> every tile of the image matters
+    Wm = (W.view(1, 64, 128, 3) * m).reshape(B, P, 3)
+    plan = make_plan(spec, "bf16")
+    fp = flat_params(spec, params).to(dev)
+    Zd, Dd, Td, Wd = Z.to(dev), D.to(dev), T.to(dev), Wm.to(dev)
+    a, b_ = 1e-7, 1e-4
+
+    def run(sparse, sel=slice(0, B)):
+        lt, dZ, _, _ = plan.forward_loss_backward(Zd[sel], Dd, fp, Td[sel], Wd[sel], loss_kind="test", alpha=a, beta=b_, need_dw=False,
+                                                  sparse_weight=sparse)
+        return lt.cpu(), dZ.cpu()
+
+    lt_d, dZ_d = run(False)
+    lt_s, dZ_s = run(True)
+    assert torch.equal(lt_s, lt_d) and torch.equal(dZ_s, dZ_d)
+    assert torch.isfinite(dZ_s).all() and float(dZ_s[0].abs().max()) > 0
+    # the all-zero weight: nothing but the prior's gradient, 2 alpha Z
+    assert torch.allclose(dZ_s[2], 2 * a * Z[2], rtol=1e-6, atol=0)
+    for k in range(B):  # image by image (other lists, other workgroups): the same numbers
+        lt_k, dZ_k = run(True, slice(k, k + 1))
+        assert torch.equal(dZ_k[0], dZ_s[k]), k
+    # and against the oracle (the reference's dense arithmetic) for the block-masked image
+    ref = O.fwd_loss_bwd(spec, params, Z[0:1], D, T[0:1], Wm[0:1], "test", a, b_, need_dw=False)
+    lt_0, dZ_0 = run(True, slice(0, 1))
+    for i in range(4):
+        assert abs(float(lt_0[i]) - ref["loss_terms"][i]) <= 3e-3 * abs(ref["loss_terms"][0]), (i, lt_0, ref["loss_terms"])
+    assert O.rel_l2(dZ_0.numpy(), ref["dZ"].numpy()) <= 3e-2
+    # the flag is ignored where it does not apply (training: RENI_NEED_DW) -- same results as without it
+    g1 = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd, sparse_weight=True)
+    g0 = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd)
+    assert torch.equal(g1[0], g0[0]) and torch.equal(g1[1], g0[1]) and torch.equal(g1[2], g0[2])
+
+
 def test_reni_forward_is_the_models_forward(dev):
     """RENI.forward(z) (RENI_module.py:75-78): the module's own inference entry -- the model on the module's grid, for the
     two tensor forms the reference's body (z.size(0)) admits: a latent tensor and a 1-D index tensor."""
