@@ -130,7 +130,8 @@ class TrainEngine:
                 # (the batch's latent rows are gathered inside the prologue kernel: no separate Z[idx] gather)
                 terms, dZ, dparams, _ = self.plan.forward_loss_backward(
                     self.latent.data, directions, self.flat, target, weight, loss_kind=self.loss_kind, alpha=self.alpha,
-                    beta=self.beta, need_dw=self.train_decoder, need_dz=True, idx=idx, sparse_weight=self.sparse_weight)
+                    beta=self.beta, need_dw=self.train_decoder, need_dz=True, idx=idx,
+                    **({"sparse_weight": True} if self.sparse_weight else {}))
             finally:
                 if hook:
                     _lib.check(_lib.load().reni_set_grad_ready_event(None))
