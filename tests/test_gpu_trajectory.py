@@ -45,7 +45,7 @@ def _band(ref, autocast):
     return min(max(FLOOR, 3.0 * dev_ac), CAP)
 
 
-def _run_g14(dtype, dev):
+def _run_g14(dtype, dev, sparse=False):
     from reni_amd.engine import TrainEngine
     from reni_amd.models import RENIAutoDecoder
     from reni_amd.utils import get_directions, get_sineweight
@@ -59,7 +59,7 @@ def _run_g14(dtype, dev):
     S = (get_sineweight(W) * torch.from_numpy(g["mask"])).to(dev)
     imgs = torch.from_numpy(g["imgs"]).to(dev)
     P = D.shape[1]
-    eng = TrainEngine(m, lr=float(g["lr"]), loss_kind="test", alpha=float(g["alpha"]), beta=float(g["beta"]))
+    eng = TrainEngine(m, lr=float(g["lr"]), loss_kind="test", alpha=float(g["alpha"]), beta=float(g["beta"]), sparse_weight=sparse)
     idx = torch.arange(N, device=dev)
     tgt = imgs.permute(0, 2, 3, 1).view(N, P, 3)   # the reference's permute + view (RENI_module.py:83-84), never copied
     terms, snaps = [], {}
@@ -103,6 +103,17 @@ def test_c4_latent_trajectory_bf16_g14():
     assert cos[20] >= 0.98, cos
     for k in (100, 200):
         assert cos[k] >= 0.5 * cos_ac[k], (k, cos, cos_ac)
+
+
+def test_c4_latent_trajectory_with_sparse_weight_is_the_same_trajectory_g14():
+    """RENI_WEIGHT_SPARSE (what RENI.training_step sets with a mask): Mask-3's zero-weight tiles and the statistics pass of its
+    constant cosine term are left out -- and all 200 Adam(0.1) steps, losses and latents, come out EQUAL to the dense run's."""
+    dev = torch.device("cuda:0")
+    _, terms_d, snaps_d = _run_g14("bf16", dev)
+    _, terms_s, snaps_s = _run_g14("bf16", dev, sparse=True)
+    assert np.array_equal(terms_s, terms_d)
+    for k in (20, 100, 200):
+        assert np.array_equal(snaps_s[k], snaps_d[k]), k
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
