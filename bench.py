@@ -292,7 +292,7 @@ def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None,
             eng = TrainEngine(model, lr=1e-5, comm=comm, fused_step=not args.no_fused_step)
             weight = sineweight
         else:
-            # the notebook's inpainting mask (examples.ipynb cell 4: data/Masks/Mask-3.png, rows 20-92 x columns 81-164 of 128 x 256
+            # the notebook's inpainting mask (examples.ipynb cell 4: data/Masks/Mask-3.png, rows 20-93 x columns 81-164 of 128 x 256
             # kept = 18.8 % of the pixels), multiplied into the sine weight (RENI_module.py:92-94)
             weight = sineweight * mask3(W_IMG).to(dev)
             # sparse_weight: what RENI.training_step passes whenever a mask is configured (lightning_module.py) -- RENI_WEIGHT_SPARSE:

@@ -204,10 +204,10 @@ def test_bench_default_line_carries_every_baseline_config_and_the_capi_exchange(
     assert set(line["also"]) == {"c4", "c4_dense", "c5", "film", "c2_b100", "c2_h256"} | curric, {k: v.get("error") for k, v in line["also"].items()}
     assert all("error" not in v for v in line["also"].values()), {k: v.get("error") for k, v in line["also"].items()}
     assert line["also"]["c2_b100"]["images_per_gpu_per_step"] == 100
-    # config 4 twice: with RENI_WEIGHT_SPARSE (what RENI.training_step passes with a mask; Mask-3: 146 of 256 tiles per image carry
+    # config 4 twice: with RENI_WEIGHT_SPARSE (what RENI.training_step passes with a mask; Mask-3: 148 of 256 tiles per image carry
     # weight, pixel 0 is masked -> no statistics pass) and dense; the sparse record's roofline counts visited tiles only
     sp, de = line["also"]["c4"]["weight_sparsity"], line["also"]["c4_dense"]["weight_sparsity"]
-    assert sp["flag"] == "RENI_WEIGHT_SPARSE" and abs(sp["tiles_visited"] - 146 / 256) < 1e-6 and not sp["cosine_term_live"]
+    assert sp["flag"] == "RENI_WEIGHT_SPARSE" and abs(sp["tiles_visited"] - 148 / 256) < 1e-6 and not sp["cosine_term_live"]
     assert de["flag"] == "off" and de["tiles_visited"] == 1.0 and abs(de["pixels_with_weight"] - 0.188) < 2e-3
     assert line["also"]["c4"]["ms_per_step"] < 0.8 * line["also"]["c4_dense"]["ms_per_step"]
     assert "stats_pass_avg_ms" in line["also"]["c4_dense"]["roofline"]

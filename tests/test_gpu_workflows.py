@@ -407,7 +407,7 @@ def test_sparse_weight_leaves_out_only_exact_zeros(dev):
     params, Z, D, W, T = random_problem(spec, B, 0, seed=91, grid_w=128)      # 64 x 128 = 8 192 directions = 64 tiles per image
     P = D.shape[1]
     m = torch.zeros(B, 64, 128, 1)
-    m[0, 10:46, 40:83] = 1.0            # Mask-3's block at this resolution (rows 20-92 x columns 81-164 of 128 x 256)
+    m[0, 10:46, 40:83] = 1.0            # Mask-3's block at this resolution (rows 20-93 x columns 81-164 of 128 x 256)
     m[1] = 1.0                          # no mask
     m[3, 33, 77] = 1.0                  # one pixel
     m[4, 10:46, 40:83] = 1.0
