@@ -30,6 +30,16 @@ def test_library_exports_every_declared_symbol():
         assert getattr(lib, name) is not None
 
 
+def test_binding_constants_are_the_headers():
+    """The flag / enum values the Python binding passes are the ones include/reni_hip.h defines (a drifted constant would select
+    another behaviour silently: RENI_WEIGHT_SPARSE is a bit of the same word as RENI_NEED_DW / RENI_NEED_DZ)."""
+    header = open(os.path.join(ROOT, "include", "reni_hip.h")).read()
+    defs = {k: int(v.rstrip("u")) for k, v in re.findall(r"#define\s+(RENI_[A-Z_0-9]+)\s+(\d+u?)\b", header)}
+    assert defs["RENI_NEED_DW"] == _lib.NEED_DW and defs["RENI_NEED_DZ"] == _lib.NEED_DZ and defs["RENI_WEIGHT_SPARSE"] == _lib.WEIGHT_SPARSE
+    assert len({_lib.NEED_DW, _lib.NEED_DZ, _lib.WEIGHT_SPARSE}) == 3 and (_lib.NEED_DW | _lib.NEED_DZ) & _lib.WEIGHT_SPARSE == 0
+    assert defs["RENI_LOSS_MSE"] == _lib.LOSS_MSE and defs["RENI_LOSS_TEST"] == _lib.LOSS_TEST
+
+
 def test_plan_validation_and_counts():
     from reni_amd.ops import Plan
     p = Plan("SO2", 36, 128, 5, 3, True, "tanh", 30.0, 30.0, "bf16")
