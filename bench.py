@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32"], help="c2 / c4: bf16, c5: f32")
     ap.add_argument("--res", default=None, help="c2 only: HxW of the equirect grid (e.g. 16x32: one stage of the curriculum on its own)")
     ap.add_argument("--dense", action="store_true", help="c4: RENI_WEIGHT_SPARSE off (every tile, and the statistics pass)")
+    ap.add_argument("--pixels", action="store_true", help="c4: RENI_WEIGHT_COMPACT (pixels with weight packed into each image's first tiles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-also", action="store_true", help="skip the c4 / c5 / film sub-records of the default (c2) line")
@@ -232,7 +233,8 @@ def mask3(sidelen):
     return mask_from_array(sidelen, src)
 
 
-def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None, defer=False, res=None, hidden=128, eq="SO2", dense=False):
+def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None, defer=False, res=None, hidden=128, eq="SO2", dense=False,
+               pixels=False):
     """One bench configuration in this process: build the model / engine, warm up, time `steps` steps between barriers.
     Returns the record (value, ms_per_step, roofline ...) on every rank; timing is the MAX over ranks.
     res = (height, width) of the c2 step's images (the multi-resolution curriculum), hidden = the SIREN's width."""
@@ -298,14 +300,17 @@ def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None,
             # sparse_weight: what RENI.training_step passes whenever a mask is configured (lightning_module.py) -- RENI_WEIGHT_SPARSE:
             # tiles whose 128 pixels all have zero weight, and the statistics pass of images whose pixel-0 weight is zero, cannot
             # change the result and are left out (on the device, from the weight, every call).  dense=True: the flag off.
-            eng = TrainEngine(model, lr=1e-1, loss_kind="test", alpha=1e-7, beta=1e-4, sparse_weight=not dense)
+            # pixels=True: RENI_WEIGHT_COMPACT -- the pixels with weight are also packed into each image's first tiles (equal to rounding)
+            eng = TrainEngine(model, lr=1e-1, loss_kind="test", alpha=1e-7, beta=1e-4, sparse_weight=("pixels" if pixels else not dense))
             wz = (weight.reshape(-1, 3) != 0).any(1)                                  # (host-side bookkeeping for the record only)
             cos_live = bool(wz[0])
             tiles = torch.nn.functional.pad(wz, (0, (-wz.numel()) % 128)).view(-1, 128).any(1)
-            sparsity = {"flag": "RENI_WEIGHT_SPARSE" if not dense else "off",
+            n_live = int(wz.sum())
+            sparsity = {"flag": "RENI_WEIGHT_COMPACT" if pixels else "RENI_WEIGHT_SPARSE" if not dense else "off",
                         "pixels_with_weight": float(wz.float().mean()), "tiles_with_weight": float(tiles.float().mean()),
                         "cosine_term_live": cos_live,
-                        "tiles_visited": 1.0 if (dense or cos_live) else float(tiles.float().mean()),
+                        "tiles_visited": 1.0 if (dense or cos_live) else (((n_live + 127) // 128) / tiles.numel() if pixels
+                                                                           else float(tiles.float().mean())),
                         "statistics_pass": "run" if (dense or cos_live) else "skipped on the device (pixel-0 weight is zero: the term is a constant)"}
 
         def step(s):
@@ -450,6 +455,8 @@ def sub_record(name, args, rank, world, dev):
         m = run_config("c2", args, rank, world, dev, batch=100, res=(h, w), **kw)
     elif name == "c4_dense":  # config 4 with RENI_WEIGHT_SPARSE off: every tile, and the statistics pass (the figure of rounds 1-3)
         m = run_config("c4", args, rank, world, dev, dense=True, **kw)
+    elif name == "c4_pixels":  # config 4 with RENI_WEIGHT_COMPACT: the pixels with weight packed into each image's first tiles
+        m = run_config("c4", args, rank, world, dev, pixels=True, **kw)
     elif name == "c2_h256":   # the width of the reference's shipped configs (configs/default.py:13)
         m = run_config("c2", args, rank, world, dev, hidden=256, **kw)
     else:
@@ -461,7 +468,7 @@ def sub_record(name, args, rank, world, dev):
     r = min(wins, key=lambda x: x["ms_per_step"])
     out = {"metric": METRIC_FWD if name == "c5" else METRIC_TRAIN.replace("128x256", "%dx%d" % tuple(int(x) for x in name[10:].split("x")))
            if name.startswith("c2_curric_") else METRIC_TRAIN,
-           "value": r["value"] / (world if name in ("c4", "c4_dense", "c5") else 1), "unit": "samples/s",
+           "value": r["value"] / (world if name in ("c4", "c4_dense", "c4_pixels", "c5") else 1), "unit": "samples/s",
            "ms_per_step": r["ms_per_step"], "ms_per_step_windows": [w_["ms_per_step"] for w_ in wins],
            "steps": r["steps"], "launches_per_step": r["launches_per_step"],
            "dtype": r["dtype"], "workload": r["config"]["workload"],
@@ -505,7 +512,7 @@ def main():
         head = run_config("c2", args, rank, world, dev, batch=args.batch, hidden=256, defer=True)
     else:
         res = tuple(int(x) for x in args.res.split("x")) if (args.res and cfg == "c2") else None
-        head = run_config(cfg, args, rank, world, dev, batch=args.batch, res=res, defer=True, dense=args.dense)  # set-up only
+        head = run_config(cfg, args, rank, world, dev, batch=args.batch, res=res, defer=True, dense=args.dense, pixels=args.pixels)  # set-up only
     # THE headline: W warm-up + K timed steps, first, identically with and without the sub-records
     rec = head()
     if cfg == "c2" and not args.no_also:
@@ -514,7 +521,7 @@ def main():
         # configurations whose ranks are independent (c4, c5: rank 0's own replica).
         also = {}
         user_dtype = args.dtype
-        names = (("c4", "c4_dense", "c5", "film", "c2_b100") + tuple(f"c2_curric_{h}x{w}" for h, w in CURRIC) + ("c2_h256",)) if world == 1 else ("c4", "c5")
+        names = (("c4", "c4_dense", "c4_pixels", "c5", "film", "c2_b100") + tuple(f"c2_curric_{h}x{w}" for h, w in CURRIC) + ("c2_h256",)) if world == 1 else ("c4", "c5")
         for c in names:
             args.dtype = None
             try:

@@ -18,7 +18,7 @@ EQ = {"None": 0, None: 0, "SO2": 1, "SO3": 2}
 ACT = {None: 0, "None": 0, "none": 0, "tanh": 1, "exp": 2}
 DTYPE = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 LOSS_MSE, LOSS_TEST = 0, 1
-NEED_DW, NEED_DZ, WEIGHT_SPARSE = 1, 2, 4
+NEED_DW, NEED_DZ, WEIGHT_SPARSE, WEIGHT_COMPACT = 1, 2, 4, 8
 COND_CONCAT, COND_FILM = 0, 1
 
 # every symbol include/reni_hip.h declares (tests check the library exports all of them)

@@ -74,6 +74,10 @@ struct MainArgs {
   // number -- built on the device from the loss weight by k_tile_flags / k_tile_compact.  NULL: every tile.
   const int* tlist;
   const int* tcount;
+  // RENI_WEIGHT_COMPACT: the image's pixels with a non-zero weight, ascending, packed into its first tiles: position k of image b is
+  // pixel plist[b * P + k], k < nlive[b] (k_pix_scatter).  NULL: position = pixel.
+  const int* plist;
+  const int* nlive;
 };
 
 // sets reni_last_error()'s thread-local message and returns `code` (defined next to the C ABI, reni_capi.inc)

@@ -23,7 +23,7 @@ if os.environ.get("RENI_ROCTX"):
 
 class TrainEngine:
     def __init__(self, model, lr: float, loss_kind: str = "mse", alpha: float = 0.0, beta: float = 0.0, comm=None,
-                 overlap_comm: bool = False, fused_step: bool = True, sparse_weight: bool = False):
+                 overlap_comm: bool = False, fused_step: bool = True, sparse_weight=False):
         """comm: an optional ``dist.RcclComm``; the decoder-gradient all-reduce then goes through the library's own
         ``reni_allreduce_grads`` on the compute stream instead of torch.distributed's nccl backend (the same RCCL ring
         either way).
@@ -33,7 +33,8 @@ class TrainEngine:
         Same sums, element for element (tests/test_gpu_dist.py); what it hides on xGMI is unmeasured (no multi-GPU box so far),
         so it is off by default."""
         self.comm = comm
-        # sparse_weight: the step's weight carries an inpainting mask (RENI_module.py:92-94): RENI_WEIGHT_SPARSE, see ops.Plan
+        # sparse_weight: the step's weight carries an inpainting mask (RENI_module.py:92-94): True = RENI_WEIGHT_SPARSE (bit-equal),
+        # "pixels" = RENI_WEIGHT_COMPACT (equal to rounding), see ops.Plan.forward_loss_backward
         self.sparse_weight = sparse_weight
         self.overlap_comm = overlap_comm
         # fused_step: one process, trainable concat decoder -> the whole step is ONE library call (reni_train_step_rows: Adam and the
@@ -131,7 +132,7 @@ class TrainEngine:
                 terms, dZ, dparams, _ = self.plan.forward_loss_backward(
                     self.latent.data, directions, self.flat, target, weight, loss_kind=self.loss_kind, alpha=self.alpha,
                     beta=self.beta, need_dw=self.train_decoder, need_dz=True, idx=idx,
-                    **({"sparse_weight": True} if self.sparse_weight else {}))
+                    **({"sparse_weight": self.sparse_weight} if self.sparse_weight else {}))
             finally:
                 if hook:
                     _lib.check(_lib.load().reni_set_grad_ready_event(None))

@@ -266,7 +266,7 @@ class _RENIConcatBase(nn.Module):
         """criterion(model(Z, D), target, weight[, Z]) as ONE fused forward+loss+backward launch.
         Returns the 4-vector (loss, mse, prior, cosine); ``.backward()`` on element 0 delivers the
         gradients the kernel already computed."""
-        return _FusedLossFn.apply(self, loss_kind, float(alpha), float(beta), bool(sparse_weight), target, weight, Z, directions,
+        return _FusedLossFn.apply(self, loss_kind, float(alpha), float(beta), sparse_weight, target, weight, Z, directions,
                                   *self._net_params())
 
     # ---- checkpoint remap (RENI.py:190-203 / 347-360) -----------------------------------------

@@ -141,7 +141,9 @@ class Plan:
         kernel: reni_forward_loss_backward_rows); dZ stays [B,ND,3] in batch order.  An index outside the table makes the
         call's loss and gradients NaN (no out-of-bounds read, no host synchronisation to check it).
         sparse_weight: the weight is zero over whole regions (an inpainting mask, RENI_module.py:92-94): RENI_WEIGHT_SPARSE --
-        the frozen-decoder persistent kernels then leave out the tiles (and the statistics pass) that cannot change the result."""
+        the frozen-decoder persistent kernels then leave out the tiles (and the statistics pass) that cannot change the result --
+        bit-equal to the dense call.  sparse_weight="pixels": RENI_WEIGHT_COMPACT -- the pixels with weight are also packed into
+        each image's first tiles (fewer tiles still; the sums are re-associated: equal to fp32 rounding)."""
         _require_cuda(Z, D, params, target, weight, idx)
         Z = _f32c(Z); params = _f32c(params)
         self._check_zp(Z, params)
@@ -160,7 +162,10 @@ class Plan:
         weight = weight.expand(B, P, 3)
         ts = (ctypes.c_int64 * 3)(*target.stride())
         wst = (ctypes.c_int64 * 3)(*weight.stride())
-        flags = (_lib.NEED_DW if need_dw else 0) | (_lib.NEED_DZ if need_dz else 0) | (_lib.WEIGHT_SPARSE if sparse_weight else 0)
+        if sparse_weight not in (False, True, None, "tiles", "pixels"):
+            raise ValueError('sparse_weight must be False, True / "tiles", or "pixels"')
+        flags = ((_lib.NEED_DW if need_dw else 0) | (_lib.NEED_DZ if need_dz else 0)
+                 | (_lib.WEIGHT_COMPACT if sparse_weight == "pixels" else _lib.WEIGHT_SPARSE if sparse_weight else 0))
         dev = Z.device
         loss_terms = torch.empty(4, dtype=torch.float32, device=dev)
         dZ = torch.empty(B, self.ndims, 3, dtype=torch.float32, device=dev) if need_dz else None

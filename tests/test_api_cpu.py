@@ -36,7 +36,9 @@ def test_binding_constants_are_the_headers():
     header = open(os.path.join(ROOT, "include", "reni_hip.h")).read()
     defs = {k: int(v.rstrip("u")) for k, v in re.findall(r"#define\s+(RENI_[A-Z_0-9]+)\s+(\d+u?)\b", header)}
     assert defs["RENI_NEED_DW"] == _lib.NEED_DW and defs["RENI_NEED_DZ"] == _lib.NEED_DZ and defs["RENI_WEIGHT_SPARSE"] == _lib.WEIGHT_SPARSE
-    assert len({_lib.NEED_DW, _lib.NEED_DZ, _lib.WEIGHT_SPARSE}) == 3 and (_lib.NEED_DW | _lib.NEED_DZ) & _lib.WEIGHT_SPARSE == 0
+    assert defs["RENI_WEIGHT_COMPACT"] == _lib.WEIGHT_COMPACT
+    bits = [_lib.NEED_DW, _lib.NEED_DZ, _lib.WEIGHT_SPARSE, _lib.WEIGHT_COMPACT]
+    assert all(b & (b - 1) == 0 for b in bits) and len(set(bits)) == 4   # four distinct bits of one word
     assert defs["RENI_LOSS_MSE"] == _lib.LOSS_MSE and defs["RENI_LOSS_TEST"] == _lib.LOSS_TEST
 
 

@@ -201,7 +201,7 @@ def test_bench_default_line_carries_every_baseline_config_and_the_capi_exchange(
     the C ABI's reni_allreduce_grads (here a one-rank communicator: the same call path as N > 1)."""
     line = _run_bench({}, "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     curric = {"c2_curric_16x32", "c2_curric_32x64", "c2_curric_64x128"}   # configs/experiment.yaml:29-34, B = 100
-    assert set(line["also"]) == {"c4", "c4_dense", "c5", "film", "c2_b100", "c2_h256"} | curric, {k: v.get("error") for k, v in line["also"].items()}
+    assert set(line["also"]) == {"c4", "c4_dense", "c4_pixels", "c5", "film", "c2_b100", "c2_h256"} | curric, {k: v.get("error") for k, v in line["also"].items()}
     assert all("error" not in v for v in line["also"].values()), {k: v.get("error") for k, v in line["also"].items()}
     assert line["also"]["c2_b100"]["images_per_gpu_per_step"] == 100
     # config 4 twice: with RENI_WEIGHT_SPARSE (what RENI.training_step passes with a mask; Mask-3: 148 of 256 tiles per image carry
@@ -211,7 +211,10 @@ def test_bench_default_line_carries_every_baseline_config_and_the_capi_exchange(
     assert de["flag"] == "off" and de["tiles_visited"] == 1.0 and abs(de["pixels_with_weight"] - 0.188) < 2e-3
     assert line["also"]["c4"]["ms_per_step"] < 0.8 * line["also"]["c4_dense"]["ms_per_step"]
     assert "stats_pass_avg_ms" in line["also"]["c4_dense"]["roofline"]
-    for c, flop in (("c4", 348448), ("c4_dense", 348448), ("c5", 177860), ("film", 424480), ("c2_h256", 2028320)):
+    px = line["also"]["c4_pixels"]["weight_sparsity"]
+    assert px["flag"] == "RENI_WEIGHT_COMPACT" and abs(px["tiles_visited"] - 49 / 256) < 1e-6
+    assert line["also"]["c4_pixels"]["ms_per_step"] < line["also"]["c4"]["ms_per_step"]
+    for c, flop in (("c4", 348448), ("c4_dense", 348448), ("c4_pixels", 348448), ("c5", 177860), ("film", 424480), ("c2_h256", 2028320)):
         r = line["also"][c]
         assert r["value"] > 0 and r["ms_per_step"] > 0 and r["roofline"]["flop_per_sample"] == flop and r["roofline"]["kernel_avg_ms"] > 0
     for c in curric:

@@ -438,6 +438,18 @@ def test_sparse_weight_leaves_out_only_exact_zeros(dev):
     for i in range(4):
         assert abs(float(lt_0[i]) - ref["loss_terms"][i]) <= 3e-3 * abs(ref["loss_terms"][0]), (i, lt_0, ref["loss_terms"])
     assert O.rel_l2(dZ_0.numpy(), ref["dZ"].numpy()) <= 3e-2
+    # RENI_WEIGHT_COMPACT: the pixels with weight packed into each image's first tiles -- the same terms in another order: equal to
+    # fp32 rounding (not bit for bit), bit-identical run to run, and image by image whatever the batch
+    lt_p, dZ_p = run("pixels")
+    lt_p2, dZ_p2 = run("pixels")
+    assert torch.equal(lt_p, lt_p2) and torch.equal(dZ_p, dZ_p2)
+    assert torch.allclose(lt_p, lt_d, rtol=2e-6, atol=0), (lt_p, lt_d)
+    for k in range(B):
+        ref_k = dZ_d[k]
+        assert float((dZ_p[k] - ref_k).norm()) <= 2e-6 * float(ref_k.norm()) + 1e-12, (k, float((dZ_p[k] - ref_k).norm()), float(ref_k.norm()))
+        lt_k, dZ_k = run("pixels", slice(k, k + 1))
+        assert torch.equal(dZ_k[0], dZ_p[k]), k
+    assert torch.equal(dZ_p[1], dZ_d[1]) and torch.equal(dZ_p[4], dZ_d[4])   # cosine term live: every pixel, in order -- the dense sums
     # the flag is ignored where it does not apply (training: RENI_NEED_DW) -- same results as without it
     g1 = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd, sparse_weight=True)
     g0 = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd)
