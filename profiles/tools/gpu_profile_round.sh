@@ -25,6 +25,8 @@ for c in c2 c4 c5 film c2_curric c2_h256; do
   X="--config $c --no-cpu-baseline"; [ $c = c2 ] && X="--steps 20 --warmup 5"   # (c2: exactly the driver's command)
   python bench.py $X > $O/bench_$c.json 2>> $O/bench.err; cut -c1-200 $O/bench_$c.json
 done
+python bench.py --config c4 --dense --no-cpu-baseline > $O/bench_c4_dense.json 2>> $O/bench.err    # RENI_WEIGHT_SPARSE off
+python bench.py --config c4 --pixels --no-cpu-baseline > $O/bench_c4_pixels.json 2>> $O/bench.err  # RENI_WEIGHT_COMPACT
 for c in c2 c4 c5 film; do
   # c2: the DEFAULT command as the driver runs it (the headline's 5 + 20 steps first, the sub-records, the same steps again): the
   # summary's last two lines are the averages of the headline's and of the sustained window's 20 timed launches
