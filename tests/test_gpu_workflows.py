@@ -450,6 +450,11 @@ def test_sparse_weight_leaves_out_only_exact_zeros(dev):
         lt_k, dZ_k = run("pixels", slice(k, k + 1))
         assert torch.equal(dZ_k[0], dZ_p[k]), k
     assert torch.equal(dZ_p[1], dZ_d[1]) and torch.equal(dZ_p[4], dZ_d[4])   # cosine term live: every pixel, in order -- the dense sums
+    # an output image is wanted: nothing may be left out (it would have holes) -- the flags are ignored, the image is the dense one
+    o_d = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd, loss_kind="test", alpha=a, beta=b_, need_dw=False, want_out=True)
+    for mode in (True, "pixels"):
+        o_s = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd, loss_kind="test", alpha=a, beta=b_, need_dw=False, want_out=True, sparse_weight=mode)
+        assert torch.equal(o_s[3], o_d[3]) and torch.equal(o_s[1], o_d[1]) and torch.equal(o_s[0], o_d[0])
     # the flag is ignored where it does not apply (training: RENI_NEED_DW) -- same results as without it
     g1 = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd, sparse_weight=True)
     g0 = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd)
