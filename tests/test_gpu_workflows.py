@@ -423,15 +423,21 @@ def test_sparse_weight_leaves_out_only_exact_zeros(dev):
                                                   sparse_weight=sparse)
         return lt.cpu(), dZ.cpu()
 
+    def where(x, y):  # (which images differ, and by how much: for the assertion messages)
+        return [(k, float((x[k] - y[k]).abs().max())) for k in range(x.shape[0]) if not torch.equal(x[k], y[k])]
+
     lt_d, dZ_d = run(False)
+    lt_d2, dZ_d2 = run(False)
+    assert torch.equal(lt_d2, lt_d) and torch.equal(dZ_d2, dZ_d), ("dense run to run", lt_d, lt_d2, where(dZ_d2, dZ_d))
     lt_s, dZ_s = run(True)
-    assert torch.equal(lt_s, lt_d) and torch.equal(dZ_s, dZ_d)
+    assert torch.equal(lt_s, lt_d), ("tiles: loss terms", lt_s, lt_d)
+    assert torch.equal(dZ_s, dZ_d), ("tiles: dZ", where(dZ_s, dZ_d))
     assert torch.isfinite(dZ_s).all() and float(dZ_s[0].abs().max()) > 0
     # the all-zero weight: nothing but the prior's gradient, 2 alpha Z
-    assert torch.allclose(dZ_s[2], 2 * a * Z[2], rtol=1e-6, atol=0)
+    assert torch.allclose(dZ_s[2], 2 * a * Z[2], rtol=1e-6, atol=0), "all-zero weight"
     for k in range(B):  # image by image (other lists, other workgroups): the same numbers
         lt_k, dZ_k = run(True, slice(k, k + 1))
-        assert torch.equal(dZ_k[0], dZ_s[k]), k
+        assert torch.equal(dZ_k[0], dZ_s[k]), ("tiles: image alone", k, float((dZ_k[0] - dZ_s[k]).abs().max()))
     # and against the oracle (the reference's dense arithmetic) for the block-masked image
     ref = O.fwd_loss_bwd(spec, params, Z[0:1], D, T[0:1], Wm[0:1], "test", a, b_, need_dw=False)
     lt_0, dZ_0 = run(True, slice(0, 1))
@@ -442,14 +448,14 @@ def test_sparse_weight_leaves_out_only_exact_zeros(dev):
     # fp32 rounding (not bit for bit), bit-identical run to run, and image by image whatever the batch
     lt_p, dZ_p = run("pixels")
     lt_p2, dZ_p2 = run("pixels")
-    assert torch.equal(lt_p, lt_p2) and torch.equal(dZ_p, dZ_p2)
-    assert torch.allclose(lt_p, lt_d, rtol=2e-6, atol=0), (lt_p, lt_d)
+    assert torch.equal(lt_p, lt_p2) and torch.equal(dZ_p, dZ_p2), ("pixels run to run", lt_p, lt_p2, where(dZ_p, dZ_p2))
+    assert torch.allclose(lt_p, lt_d, rtol=2e-6, atol=0), ("pixels: loss terms", lt_p, lt_d)
     for k in range(B):
         ref_k = dZ_d[k]
         assert float((dZ_p[k] - ref_k).norm()) <= 2e-6 * float(ref_k.norm()) + 1e-12, (k, float((dZ_p[k] - ref_k).norm()), float(ref_k.norm()))
         lt_k, dZ_k = run("pixels", slice(k, k + 1))
-        assert torch.equal(dZ_k[0], dZ_p[k]), k
-    assert torch.equal(dZ_p[1], dZ_d[1]) and torch.equal(dZ_p[4], dZ_d[4])   # cosine term live: every pixel, in order -- the dense sums
+        assert torch.equal(dZ_k[0], dZ_p[k]), ("pixels: image alone", k, float((dZ_k[0] - dZ_p[k]).abs().max()))
+    assert torch.equal(dZ_p[1], dZ_d[1]) and torch.equal(dZ_p[4], dZ_d[4]), "pixels, cosine term live"   # every pixel, in order -- the dense sums
     # an output image is wanted: nothing may be left out (it would have holes) -- the flags are ignored, the image is the dense one
     o_d = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd, loss_kind="test", alpha=a, beta=b_, need_dw=False, want_out=True)
     for mode in (True, "pixels"):
@@ -458,7 +464,7 @@ def test_sparse_weight_leaves_out_only_exact_zeros(dev):
     # the flag is ignored where it does not apply (training: RENI_NEED_DW) -- same results as without it
     g1 = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd, sparse_weight=True)
     g0 = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd)
-    assert torch.equal(g1[0], g0[0]) and torch.equal(g1[1], g0[1]) and torch.equal(g1[2], g0[2])
+    assert torch.equal(g1[0], g0[0]) and torch.equal(g1[1], g0[1]) and torch.equal(g1[2], g0[2]), "training call with the flag"
 
 
 def test_reni_forward_is_the_models_forward(dev):
