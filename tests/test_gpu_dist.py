@@ -209,11 +209,12 @@ def test_bench_default_line_carries_every_baseline_config_and_the_capi_exchange(
     sp, de = line["also"]["c4"]["weight_sparsity"], line["also"]["c4_dense"]["weight_sparsity"]
     assert sp["flag"] == "RENI_WEIGHT_SPARSE" and abs(sp["tiles_visited"] - 148 / 256) < 1e-6 and not sp["cosine_term_live"]
     assert de["flag"] == "off" and de["tiles_visited"] == 1.0 and abs(de["pixels_with_weight"] - 0.188) < 2e-3
-    assert line["also"]["c4"]["ms_per_step"] < 0.8 * line["also"]["c4_dense"]["ms_per_step"]
+    # (the kernels' own times, HIP events: a 0.2-0.3 ms step is host-paced on a busy host, its wall time is not a stable comparison)
+    assert line["also"]["c4"]["roofline"]["kernel_avg_ms"] < 0.8 * line["also"]["c4_dense"]["roofline"]["kernel_avg_ms"]
     assert "stats_pass_avg_ms" in line["also"]["c4_dense"]["roofline"]
     px = line["also"]["c4_pixels"]["weight_sparsity"]
     assert px["flag"] == "RENI_WEIGHT_COMPACT" and abs(px["tiles_visited"] - 49 / 256) < 1e-6
-    assert line["also"]["c4_pixels"]["ms_per_step"] < line["also"]["c4"]["ms_per_step"]
+    assert line["also"]["c4_pixels"]["roofline"]["kernel_avg_ms"] < 0.8 * line["also"]["c4"]["roofline"]["kernel_avg_ms"]
     for c, flop in (("c4", 348448), ("c4_dense", 348448), ("c4_pixels", 348448), ("c5", 177860), ("film", 424480), ("c2_h256", 2028320)):
         r = line["also"][c]
         assert r["value"] > 0 and r["ms_per_step"] > 0 and r["roofline"]["flop_per_sample"] == flop and r["roofline"]["kernel_avg_ms"] > 0
