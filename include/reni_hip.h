@@ -65,7 +65,8 @@ extern "C" {
  * may leave out work that cannot change the result -- 128-pixel tiles whose weights are all zero, and the statistics pass of
  * RENITestLoss's cosine term for images whose pixel-0 weight is zero (loss_functions.py:25-32 multiplies the term by that weight).
  * The regions are found on the device from `weight` in every call; results are the dense ones (the skipped terms are exact zeros).
- * Honoured by the frozen-decoder calls on the persistent bf16 kernels (no RENI_NEED_DW, no output image requested), ignored elsewhere. */
+ * Honoured by the frozen-decoder calls of the concat models (no RENI_NEED_DW, no output image requested; every width, fp32 and bf16),
+ * ignored elsewhere. */
 #define RENI_WEIGHT_SPARSE 4u
 /* As RENI_WEIGHT_SPARSE, and the pixels with weight are PACKED into each image's first tiles (a position -> pixel list built on the
  * device per call), so a tile is left out unless it holds such pixels: Mask-3 at 128 x 256 keeps 19 % of the pixels in 148 of 256

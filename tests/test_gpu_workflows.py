@@ -467,6 +467,44 @@ def test_sparse_weight_leaves_out_only_exact_zeros(dev):
     assert torch.equal(g1[0], g0[0]) and torch.equal(g1[1], g0[1]) and torch.equal(g1[2], g0[2]), "training call with the flag"
 
 
+@pytest.mark.parametrize("dtype,H,L", [("f32", 64, 3), ("f32", 128, 5), ("bf16", 256, 3), ("bf16", 64, 2)])
+def test_sparse_weight_on_the_generic_kernels(dev, dtype, H, L):
+    """RENI_WEIGHT_SPARSE / RENI_WEIGHT_COMPACT off the persistent path: fp32 (the parity-grade arithmetic) and the widths without a
+    persistent kernel (H = 256 is what the reference ships) walk the same device-built lists in k_reni_main -- tiles: EQUAL to the dense
+    call; pixels: equal to rounding, bit-identical run to run."""
+    spec = O.DecoderSpec(9, "SO2", H, L, 3, True, "tanh")
+    B = 4
+    params, Z, D, W, T = random_problem(spec, B, 0, seed=17, grid_w=128)
+    P = D.shape[1]
+    m = torch.zeros(B, 64, 128, 1)
+    m[0, 10:46, 40:83] = 1.0
+    m[1] = 1.0
+    m[2, 5:9, 100:128] = 1.0
+    m[2, 0, 0] = 1.0
+    Wm = (W.view(1, 64, 128, 3) * m).reshape(B, P, 3)      # image 3: all-zero weight
+    plan = make_plan(spec, dtype)
+    fp = flat_params(spec, params).to(dev)
+    Zd, Dd, Td, Wd = Z.to(dev), D.to(dev), T.to(dev), Wm.to(dev)
+
+    def run(mode):
+        lt, dZ, _, _ = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd, loss_kind="test", alpha=1e-7, beta=1e-4, need_dw=False, sparse_weight=mode)
+        return lt.cpu(), dZ.cpu()
+
+    lt_d, dZ_d = run(False)
+    lt_s, dZ_s = run(True)
+    assert torch.equal(lt_s, lt_d) and torch.equal(dZ_s, dZ_d), (lt_s, lt_d)
+    lt_p, dZ_p = run("pixels")
+    lt_p2, dZ_p2 = run("pixels")
+    assert torch.equal(lt_p, lt_p2) and torch.equal(dZ_p, dZ_p2)
+    assert torch.allclose(lt_p, lt_d, rtol=2e-6, atol=0), (lt_p, lt_d)
+    for k in range(B):
+        assert float((dZ_p[k] - dZ_d[k]).norm()) <= 2e-6 * float(dZ_d[k].norm()) + 1e-12, k
+    ref = O.fwd_loss_bwd(spec, params, Z[0:1], D, T[0:1], Wm[0:1], "test", 1e-7, 1e-4, need_dw=False)
+    tol = 1e-5 if dtype == "f32" else 3e-2
+    assert O.rel_l2(dZ_s[0:1].numpy(), ref["dZ"].numpy()) <= tol
+    assert torch.isfinite(dZ_s).all() and float(dZ_s[0].abs().max()) > 0
+
+
 def test_reni_forward_is_the_models_forward(dev):
     """RENI.forward(z) (RENI_module.py:75-78): the module's own inference entry -- the model on the module's grid, for the
     two tensor forms the reference's body (z.size(0)) admits: a latent tensor and a 1-D index tensor."""
