@@ -239,6 +239,17 @@ int reni_film_model_backward(const reni_plan* plan, int64_t B, int64_t P, const 
 int reni_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
                    float b2, float eps, int64_t step, float grad_scale, void* stream);
 
+/* One iteration of the reference's FIT_LATENT loop -- the test-time optimisation of examples.ipynb cell 4: training_step with a fixed
+ * decoder (RENI_module.py:92-103, 126-128), loss.backward(), Adam on the latent table (:178-192) -- in one call:
+ * reni_forward_loss_backward_rows with flags = RENI_NEED_DZ | `flags`, THEN reni_adam_rows_step(Z_table, dZ, idx, ...) with
+ * grad_scale 1 -- same arguments, same results.  `flags`: 0, RENI_WEIGHT_SPARSE or RENI_WEIGHT_COMPACT (a masked weight).
+ * Z_table, m_lat, v_lat are updated in place; dZ [B,ND,3] receives the step's gradient; concat plans, one process. */
+int reni_latent_step_rows(const reni_plan* plan, int64_t B, int64_t P, float* Z_table, int64_t n_rows, const int64_t* idx, const float* D,
+                          int64_t d_batch_stride, const float* params, const float* target, const int64_t target_strides[3],
+                          const float* weight, const int64_t weight_strides[3], int32_t loss_kind, float alpha, float beta,
+                          uint32_t flags, float* m_lat, float* v_lat, float lr, float b1, float b2, float eps, int64_t step,
+                          float* loss_terms, float* dZ, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same Adam step over a table p [n_rows][row_len] whose gradient is given for the B rows idx[0..B) only
  * (g_rows [B][row_len], idx int64 on the device; repeated indices accumulate).  All other rows have gradient zero and
  * still move by their momentum: the dense torch.optim.Adam over the whole latent table that the reference runs

@@ -114,6 +114,16 @@ class TrainEngine:
             st["expect"], st["shape"] = ((nxt.data_ptr(), nxt.numel()) if nxt is not None else None), shape
             _roctx.pop()
             return terms
+        if (self.fused_step and not self.film and not self.train_decoder and self.world == 1 and self.comm is None
+                and hasattr(self.plan, "latent_step")):
+            # a frozen concat decoder, one process: the FIT_LATENT iteration as ONE library call (reni_latent_step_rows)
+            self.t += 1
+            _roctx.push("reni.step.latent")
+            terms, _ = self.plan.latent_step(self.latent.data, idx.contiguous(), directions, self.flat, target, weight, self.m_lat,
+                                             self.v_lat, self.t, self.lr, loss_kind=self.loss_kind, alpha=self.alpha, beta=self.beta,
+                                             sparse_weight=self.sparse_weight)
+            _roctx.pop()
+            return terms
         _roctx.push("reni.step.fwd_bwd")
         if self.film:  # mapping network + fused core + glue backward in one library call (reni_film_model_*)
             n = self.plan.n_params

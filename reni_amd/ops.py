@@ -219,6 +219,39 @@ class Plan:
             dparams.data_ptr(), wp, wn, torch.cuda.current_stream(dev).cuda_stream))
         return loss_terms, dZ, dparams
 
+    def latent_step(self, Z_table, idx, D, params, target, weight, m_lat, v_lat, step, lr, loss_kind="test", alpha=0.0, beta=0.0,
+                    betas=(0.9, 0.999), eps=1e-8, sparse_weight=False):
+        """reni_latent_step_rows: one FIT_LATENT iteration (frozen decoder) -- forward_loss_backward(idx=..., need_dw=False) then
+        adam_rows_step on the table, IN PLACE, as one library call.  Returns (loss_terms[4], dZ [B,ND,3])."""
+        _require_cuda(Z_table, D, params, target, weight, idx, m_lat, v_lat)
+        for t in (Z_table, m_lat, v_lat):
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError("latent_step updates its buffers in place: contiguous float32 tensors only")
+        params = _f32c(params)
+        self._check_zp(Z_table, params)
+        if idx.dtype != torch.int64 or idx.dim() != 1 or idx.numel() < 1 or not idx.is_contiguous():
+            raise ValueError("idx must be a non-empty contiguous 1-D int64 tensor")
+        if sparse_weight not in (False, True, None, "tiles", "pixels"):
+            raise ValueError('sparse_weight must be False, True / "tiles", or "pixels"')
+        B, P, Dc, dbs = self._grid_args(Z_table[:1].expand(idx.numel(), -1, -1), D)
+        target = (target if target.dtype == torch.float32 else target.float()).expand(B, P, 3)
+        weight = (weight if weight.dtype == torch.float32 else weight.float()).expand(B, P, 3)
+        ts = (ctypes.c_int64 * 3)(*target.stride())
+        wst = (ctypes.c_int64 * 3)(*weight.stride())
+        dev = Z_table.device
+        loss_terms = torch.empty(4, dtype=torch.float32, device=dev)
+        dZ = torch.empty(B, self.ndims, 3, dtype=torch.float32, device=dev)
+        flags = _lib.WEIGHT_COMPACT if sparse_weight == "pixels" else _lib.WEIGHT_SPARSE if sparse_weight else 0
+        ws = self.workspace(B, P, _lib.NEED_DZ | flags, dev)
+        wp, wn = self._aligned_ptr(ws)
+        kind = {"mse": _lib.LOSS_MSE, "test": _lib.LOSS_TEST}[loss_kind]
+        _lib.check(self.lib.reni_latent_step_rows(
+            self._h, B, P, Z_table.data_ptr(), Z_table.shape[0], idx.data_ptr(), Dc.data_ptr(), dbs, params.data_ptr(),
+            target.data_ptr(), ts, weight.data_ptr(), wst, kind, float(alpha), float(beta), flags, m_lat.data_ptr(), v_lat.data_ptr(),
+            float(lr), float(betas[0]), float(betas[1]), float(eps), int(step), loss_terms.data_ptr(), dZ.data_ptr(), wp, wn,
+            torch.cuda.current_stream(dev).cuda_stream))
+        return loss_terms, dZ
+
     def backward(self, Z, D, params, dout, need_dw=True, need_dz=True):
         _require_cuda(Z, D, params, dout)
         Z = _f32c(Z); params = _f32c(params); dout = _f32c(dout)

@@ -74,3 +74,37 @@ def test_a_batch_other_than_the_staged_one_poisons_the_step():
     other = torch.tensor([2, 5, 7, 9], device=dev)
     t2 = e2.step(other, T[other], S, D)
     assert bool(torch.isfinite(t2).all())
+
+
+@pytest.mark.parametrize("dtype,H,L,W,sparse", [
+    ("bf16", 128, 5, 128, False), ("bf16", 128, 5, 128, True), ("bf16", 128, 5, 128, "pixels"),
+    ("f32", 64, 3, 64, True), ("bf16", 256, 2, 64, "pixels"),
+])
+def test_latent_step_is_bit_equal_to_the_two_calls(dtype, H, L, W, sparse):
+    """reni_latent_step_rows (one FIT_LATENT iteration, frozen decoder: RENITestLoss gradient of the batch's latent rows, then the
+    dense Adam step on the table) against the two calls it replaces, through TrainEngine (fused_step on / off): loss terms of every
+    step, the table and both moments bit-equal -- with a masked weight and each RENI_WEIGHT_* mode."""
+    from reni_amd.engine import TrainEngine
+    from reni_amd.models import RENIAutoDecoder
+    dev = torch.device("cuda:0")
+    N, B = 6, 4
+    D, S, T = _data(N, W, dev)
+    mask = torch.zeros(W // 2, W, 1)
+    mask[W // 8: W // 3, W // 4: (2 * W) // 3] = 1.0
+    Wm = S * mask.reshape(1, -1, 1).to(dev)
+    batches = [torch.arange(B, device=dev), torch.tensor([5, 1, 4, 2], device=dev), torch.arange(B, device=dev) + 2]
+    res = {}
+    for fused in (False, True):
+        torch.manual_seed(3)
+        m = RENIAutoDecoder(N, 9, "SO2", H, L, 3, True, "tanh", 30.0, 30.0, True)
+        with torch.no_grad():
+            m.Z.normal_(generator=torch.Generator().manual_seed(5))
+        m.set_compute_dtype(dtype).to(dev)
+        e = TrainEngine(m, lr=1e-1, loss_kind="test", alpha=1e-7, beta=1e-4, sparse_weight=sparse, fused_step=fused)
+        terms = [e.step(idx, T[idx], Wm, D).clone() for idx in batches]
+        torch.cuda.synchronize()
+        res[fused] = (torch.stack(terms), [t.detach().clone() for t in (m.Z.data, e.m_lat, e.v_lat)])
+    assert torch.equal(res[False][0], res[True][0]), (res[False][0], res[True][0])
+    for a, b, name in zip(res[False][1], res[True][1], ("Z", "m_lat", "v_lat")):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    assert torch.isfinite(res[True][0]).all() and float(res[True][1][1].abs().max()) > 0
