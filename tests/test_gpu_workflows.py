@@ -505,6 +505,43 @@ def test_sparse_weight_on_the_generic_kernels(dev, dtype, H, L):
     assert torch.isfinite(dZ_s).all() and float(dZ_s[0].abs().max()) > 0
 
 
+@pytest.mark.parametrize("dtype,H,L", [("bf16", 128, 5), ("f32", 64, 2)])
+def test_sparse_weight_with_ragged_tiles_and_broadcast_strides(dev, dtype, H, L):
+    """RENI_WEIGHT_SPARSE / _COMPACT where the bookkeeping has edges: P = 1 000 directions (seven full tiles and one of 104), per-image
+    directions, a weight that is ONE [1, P, 1] mask broadcast over batch and channels (strides 0), and a target given as a channel-
+    planar view (the reference's permute + view of [B, 3, H, W], RENI_module.py:83-84).  Tiles: equal to dense; pixels: to rounding."""
+    spec = O.DecoderSpec(9, "SO2", H, L, 3, True, "tanh")
+    B, P = 3, 1000
+    params, Z, D, W, T = random_problem(spec, B, P, seed=23, per_image_dirs=True)
+    keep = torch.zeros(1, P, 1)
+    keep[0, 130:250] = 1.0          # cuts through tiles 1 (pixels 128-255) only ...
+    keep[0, 900:1000] = 1.0         # ... and the ragged last tile; pixel 0 masked
+    Wb = (keep * 0.7).to(dev).expand(B, P, 3)
+    Tp = T.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)       # [B, P, 3] view of a [B, 3, P] buffer
+    plan = make_plan(spec, dtype)
+    fp = flat_params(spec, params).to(dev)
+    Zd, Dd = Z.to(dev), D.to(dev)
+
+    def run(mode):
+        lt, dZ, _, _ = plan.forward_loss_backward(Zd, Dd, fp, Tp, Wb, loss_kind="test", alpha=1e-7, beta=1e-4, need_dw=False, sparse_weight=mode)
+        return lt.cpu(), dZ.cpu()
+
+    lt_d, dZ_d = run(False)
+    lt_s, dZ_s = run(True)
+    assert torch.equal(lt_s, lt_d) and torch.equal(dZ_s, dZ_d), (lt_s, lt_d)
+    lt_p, dZ_p = run("pixels")
+    assert torch.allclose(lt_p, lt_d, rtol=2e-6, atol=0), (lt_p, lt_d)
+    for k in range(B):
+        assert float((dZ_p[k] - dZ_d[k]).norm()) <= 2e-6 * float(dZ_d[k].norm()) + 1e-12, k
+    ref = O.fwd_loss_bwd(spec, params, Z, D, T, (keep * 0.7).expand(B, P, 3), "test", 1e-7, 1e-4, need_dw=False)
+    assert O.rel_l2(dZ_s.numpy(), ref["dZ"].numpy()) <= (1e-5 if dtype == "f32" else 3e-2)
+    # with pixel 0 kept the cosine term is live: every tile is visited, and the three modes agree bit for bit
+    keep[0, 0] = 1.0
+    Wb = (keep * 0.7).to(dev).expand(B, P, 3)
+    a0, a1, a2 = run(False), run(True), run("pixels")
+    assert torch.equal(a0[1], a1[1]) and torch.equal(a0[1], a2[1]) and torch.equal(a0[0], a1[0]) and torch.equal(a0[0], a2[0])
+
+
 def test_reni_forward_is_the_models_forward(dev):
     """RENI.forward(z) (RENI_module.py:75-78): the module's own inference entry -- the model on the module's grid, for the
     two tensor forms the reference's body (z.size(0)) admits: a latent tensor and a 1-D index tensor."""
