@@ -302,10 +302,11 @@ class _RENIFiLMBase(_RENIConcatBase):
         net = self._net_params()
         return _FilmDecodeFn.apply(self, Z, directions, len(net), *net, *self._map_params())
 
-    def fused_loss(self, Z, directions, target, weight, loss_kind="mse", alpha=0.0, beta=0.0):
+    def fused_loss(self, Z, directions, target, weight, loss_kind="mse", alpha=0.0, beta=0.0, sparse_weight=False):
         """criterion(model(Z, D), target, weight[, Z]) as ONE library call (mapping network, fused forward+loss+
         backward, glue backward); returns (loss, mse, prior, cosine); ``.backward()`` on element 0 delivers the
-        gradients the call already computed."""
+        gradients the call already computed.  sparse_weight (a masked weight, see ops.Plan.forward_loss_backward) is accepted
+        for the concat models' signature and has no effect here: the FiLM kernels evaluate every tile."""
         ops._require_cuda(Z, directions, target, weight)
         net = self._net_params()
         return _FilmFusedLossFn.apply(self, loss_kind, float(alpha), float(beta), target, weight, Z, directions, len(net),

@@ -88,6 +88,12 @@ def test_film_golden_generic_autograd_and_test_loss(dev, tag):
     t_fused[0].backward()
     assert np.abs(t_fused.detach().cpu().numpy() - g["test_terms"]).max() <= 2e-6 * abs(g["test_terms"][0])
     assert O.rel_l2(Z2.grad.cpu().numpy(), g["test_dZ"]) <= 2e-5
+    # the criterion's fused form as RENI.training_step calls it with a mask configured (sparse_weight=True): accepted by the FiLM
+    # models too (no effect there: their kernels evaluate every tile) -- the same numbers
+    Z4 = torch.from_numpy(g["Z"]).to(dev).requires_grad_(True)
+    t_crit = RENITestLoss(alpha=1e-3, beta=1e-1).fused(m, Z4, D, T, S, sparse_weight=True)
+    t_crit[0].backward()
+    assert torch.equal(torch.stack([x.detach() for x in t_crit]), t_fused.detach()) and torch.equal(Z4.grad, Z2.grad)
     Z3 = torch.from_numpy(g["Z"]).to(dev).requires_grad_(True)
     t_torch = RENITestLoss(alpha=1e-3, beta=1e-1)(m(Z3, D), T, S, Z3)
     t_torch[0].backward()
