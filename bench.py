@@ -433,6 +433,8 @@ def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, 
                            "avg_us_on_compute_stream": comm_us}
     if args.comm == "capi":
         rec["config"]["exchange_step"] = "reni_allreduce_grads (C ABI, librccl)"
+    if eng is not None and cfg == "c4":
+        rec["config"]["step_call"] = "reni_latent_step_rows (one call: statistics pass where live + fwd + loss + bwd, Adam on the latent table)"
     if eng is not None and cfg == "c2":
         rec["config"]["step_call"] = ("reni_train_step_rows (one call: fwd+loss+bwd, Adam, next prologue)" if eng._stage is not None
                                       else "reni_forward_loss_backward_rows + reni_adam_step2")
