@@ -299,6 +299,22 @@ def test_envmap_shader_surface():
     assert abs(r.ks - 0.7) < 1e-12 and r.shininess == 500.0 and r.gbuffer.image_size == (4, 4)
 
 
+def test_mask3_geometry_behind_the_sparse_weight_records():
+    """The figures bench.py's config-4 records and DESIGN.md quote for the notebook's Mask-3 at 128 x 256 (examples.ipynb cell 4;
+    resized by get_mask's nearest rule, utils.py:81-91): rows 20-93 x columns 81-164 kept = 19.0 % of the pixels, pixel 0 masked (so
+    RENITestLoss's cosine term, which carries pixel 0's weight, is a constant), 148 of the 256 tiles of 128 consecutive pixels touched
+    (RENI_WEIGHT_SPARSE) and 49 tiles' worth of pixels (RENI_WEIGHT_COMPACT)."""
+    import bench
+    m = bench.mask3(256)
+    assert tuple(m.shape) == (1, 128 * 256, 3) and set(m.unique().tolist()) == {0.0, 1.0}
+    g = m.view(128, 256, 3)[..., 0]
+    rows, cols = g.any(1).nonzero().flatten(), g.any(0).nonzero().flatten()
+    assert (int(rows.min()), int(rows.max()), int(cols.min()), int(cols.max())) == (20, 93, 81, 164)
+    assert float(g[0, 0]) == 0.0 and abs(float(g.mean()) - 0.1897) < 1e-4
+    live = g.reshape(-1) != 0
+    assert int(live.view(-1, 128).any(1).sum()) == 148 and (int(live.sum()) + 127) // 128 == 49
+
+
 def test_pmc_traffic_record_belongs_to_the_committed_kernel_sources():
     """bench.py's `roofline.traffic` comes from profiles/pmc_traffic.json and is printed only when the record's source hash equals
     the hash of reni_amd/csrc -- a kernel edit without a new PMC pass (profiles/tools/gpu_profile_round.sh) must not go unnoticed."""
