@@ -93,8 +93,10 @@ class Plan:
         info = (ctypes.c_int32 * 8)()
         flags = (_lib.NEED_DW if need_dw else 0) | (_lib.NEED_DZ if need_dz else 0)
         _lib.check(self.lib.reni_path_info(self._h, B, P, flags, info))
-        env = [n for b, n in ((1, "RENI_NO_PERSIST"), (2, "RENI_NO_SIDE_STREAM"), (4, "RENI_FRAG_WS_CAP_MB"), (8, "RENI_DW1_OLD")) if info[6] & b]
-        return {"persistent_kernels": bool(info[0]), "dw1_kernel": ("none", "k_reni_dw1_ring", "k_reni_dw1")[info[1]],
+        env = [n for b, n in ((1, "RENI_NO_PERSIST"), (2, "RENI_NO_SIDE_STREAM"), (4, "RENI_FRAG_WS_CAP_MB"), (8, "RENI_DW1_OLD"),
+                              (16, "RENI_NO_L0X")) if info[6] & b]
+        # (k_reni_l0_ring: layer 0's backward + dW_1 behind the L0X training instance -- given, in addition, WeightedMSE and no output image)
+        return {"persistent_kernels": bool(info[0]), "dw1_kernel": ("none", "k_reni_dw1_ring", "k_reni_dw1", "k_reni_l0_ring")[info[1]],
                 "side_stream": bool(info[2]), "images_per_chunk": info[3], "operand_stream": bool(info[4]),
                 "fragment_stream": ("none", "bf16", "f32")[info[5]], "env_overrides": env, "workgroups": info[7]}
 

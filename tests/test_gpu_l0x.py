@@ -1,0 +1,58 @@
+"""Round 5: the L0X split of the config-2 training path -- k_reni_train_bf16<.., SPEC, L0X> ends a tile with layer 2's step and
+k_reni_l0_ring takes layer 1's dX GEMM, the first SineLayer's derivative, the layer-0 dA and dW_1 from the g_1 stream
+(reference: the autograd backward of src/models/RENI.py:86-87,132-178 through net[0] and net[1])."""
+import os
+
+import pytest
+import torch
+
+from oracle import reni_oracle as O
+from tests.util import flat_params, make_plan, random_problem, unflatten
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def dev():
+    return torch.device("cuda:0")
+
+
+def _plan_without_l0x(spec, dtype):
+    os.environ["RENI_NO_L0X"] = "1"  # (read once, at plan creation)
+    try:
+        return make_plan(spec, dtype)
+    finally:
+        del os.environ["RENI_NO_L0X"]
+
+
+@pytest.mark.parametrize("B,gw,P", [(8, 256, 0), (3, 64, 0), (70, 32, 0), (300, None, 128)])
+def test_l0x_split_against_the_oracle_and_round_4s_kernels(dev, B, gw, P):
+    """Config-2 architecture (ND = 36, SO2, 5 x 128, tanh, WeightedMSE): loss, dZ and every dW / db of the L0X path against the float64
+    oracle at the bf16 tolerance, and against the in-kernel layer-0 backward (RENI_NO_L0X) at a fraction of it -- the two differ only
+    in the layer-0 cosine (fp32 here, from an fp16 phase there) and the order of the sums.  Shapes: many tiles per workgroup with ranges
+    crossing images; fewer tiles than workgroups; four-tile images; one-tile images (an image run per tile, per-image directions)."""
+    spec = O.DecoderSpec(36, "SO2", 128, 5, 3, True, "tanh")
+    params, Z, D, W, T = random_problem(spec, B, P, seed=5 + B, grid_w=gw, per_image_dirs=gw is None)
+    plan = make_plan(spec, "bf16")
+    P = D.shape[1]
+    info = plan.path_info(B, P)
+    assert info["dw1_kernel"] == "k_reni_l0_ring", info
+    old = _plan_without_l0x(spec, "bf16")
+    oinfo = old.path_info(B, P)
+    assert oinfo["dw1_kernel"] == "k_reni_dw1_ring" and "RENI_NO_L0X" in oinfo["env_overrides"], oinfo
+    fp = flat_params(spec, params).to(dev)
+    Zd, Dd, Td, Wd = Z.to(dev), D.to(dev), T.to(dev), W.to(dev)
+    lt, dZ, dp, _ = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd)
+    lt, dZ, dp = lt.clone(), dZ.clone(), dp.clone()
+    lt2, dZ2, dp2, _ = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd)
+    assert torch.equal(dZ, dZ2) and torch.equal(dp, dp2) and torch.equal(lt, lt2)  # run-to-run bit-equality
+    lo, dZo, dpo, _ = old.forward_loss_backward(Zd, Dd, fp, Td, Wd)
+    assert abs(float(lt[0]) - float(lo[0])) <= 1e-6 * abs(float(lo[0]))  # the forward pass is the same code
+    assert O.rel_l2(dZ.cpu().numpy(), dZo.cpu().numpy()) <= 2e-3
+    assert O.rel_l2(dp.cpu().numpy(), dpo.cpu().numpy()) <= 2e-3
+    ref = O.factored_fwd_bwd(spec, {k: v.numpy() for k, v in params.items()}, Z.numpy(), D.numpy(), T.numpy(), W.numpy())
+    assert abs(float(lt[0]) - ref["loss_terms"][0]) <= 2e-3 * abs(ref["loss_terms"][0])
+    assert O.rel_l2(dZ.cpu().numpy(), ref["dZ"]) <= 3e-2
+    gp = unflatten(spec, dp.cpu())
+    for k in gp:  # (the first layer -- through dA -- and layer 1 are the two pieces k_reni_l0_ring owns)
+        assert O.rel_l2(gp[k].numpy(), ref["grads"][k]) <= 3e-2, (k, O.rel_l2(gp[k].numpy(), ref["grads"][k]))
