@@ -166,16 +166,39 @@ int reni_forward_loss_backward_rows(const reni_plan* plan, int64_t B, int64_t P,
  *     UPDATED decoder) is run at the end of this call, so the next call starts with its main kernel.
  * `stage_state` (in / out, zero before the first call) says whether -- and into which of two copies -- the previous call staged this
  * call's prologue.  The caller resets it to zero whenever it changes B, P, `params` or `Z_table` between two calls, and passes as
- * idx what it announced as `idx_next`: the library checks the indices on the device and turns a step whose batch is not the staged one
- * into NaN (loss and gradients).  idx_next = NULL: nothing is staged (the next call runs its own prologue).  Z_table and params are
- * updated in place; dZ [B,ND,3] and dparams receive the step's gradients as reni_forward_loss_backward_rows returns them.  Single
- * process only: a data-parallel step has its all-reduce between the two halves and uses the two separate entry points. */
+ * idx what it announced as `idx_next`: the library checks the indices on the device -- on every path, persistent and generic kernels alike --
+ * and SKIPS a step whose batch is not the staged one, loudly: loss terms and the latent gradient come out NaN, and parameters,
+ * latent table and all four Adam moments stay exactly as they were (the optimiser launch reads the check's flag).  The staged copies
+ * live in `workspace`: ANY other library call that is given the same workspace between two calls of this function (a validation
+ * forward, a fused loss, another B or P) overwrites them -- reset `stage_state` to zero after such a call (reni_amd/ops.py counts
+ * its workspace hand-outs and does).  idx_next = NULL: nothing is staged (the next call runs its own prologue).  Z_table and params are
+ * updated in place; dZ [B,ND,3] and dparams receive the step's gradients as reni_forward_loss_backward_rows returns them.  One
+ * process; the data-parallel step is reni_train_step_rows_dp below. */
 int reni_train_step_rows(const reni_plan* plan, int64_t B, int64_t P, float* Z_table, int64_t n_rows, const int64_t* idx,
                          const int64_t* idx_next, const float* D, int64_t d_batch_stride, float* params, const float* target,
                          const int64_t target_strides[3], const float* weight, const int64_t weight_strides[3], int32_t loss_kind,
                          float alpha, float beta, float* m_dec, float* v_dec, float* m_lat, float* v_lat, float lr, float b1,
                          float b2, float eps, int64_t step, float grad_scale, uint32_t* stage_state, float* loss_terms, float* dZ,
                          float* dparams, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same step for one rank of a DATA-PARALLEL job (BASELINE config 3; the reference: PyTorch-Lightning's DDP strategy, run.py:97-110,
+ * whose all-reduce averages the shared decoder's gradients over the ranks between backward and optimizer.step): everything
+ * reni_train_step_rows does, with the exchange INSIDE the call -- fwd + loss + bwd, the partial reductions, an in-place RCCL
+ * all-reduce(sum) of the flat decoder gradient on `comm` (reni_rccl_comm_create; the caller's stream), the one optimiser launch with
+ * `grad_scale` (pass 1 / world_size: the mean), the next batch's prologue.  Same launches as the one-process step plus layer 1's
+ * partial reduction (its sum must be in the gradient buffer before the collective) plus the collective.  The latent table needs no
+ * exchange: every image's row has exactly one owner (reni_amd/dist.py).  dparams returns the SUM over the ranks.
+ * overlap != 0: the gradient of layers >= 2 + head (final before the ring kernel runs) is all-reduced on the library's own
+ * communication stream beside the rest of the backward pass, the remainder (first layer, layer 1) behind it on the caller's stream --
+ * two collectives on `comm`, issued in the same order on every rank; element for element the same sums.
+ * With a one-rank communicator the results are bit-equal to reni_train_step_rows (tests/test_gpu_dist.py). */
+int reni_train_step_rows_dp(const reni_plan* plan, int64_t B, int64_t P, float* Z_table, int64_t n_rows, const int64_t* idx,
+                            const int64_t* idx_next, const float* D, int64_t d_batch_stride, float* params, const float* target,
+                            const int64_t target_strides[3], const float* weight, const int64_t weight_strides[3],
+                            int32_t loss_kind, float alpha, float beta, float* m_dec, float* v_dec, float* m_lat, float* v_lat,
+                            float lr, float b1, float b2, float eps, int64_t step, float grad_scale, void* comm, int32_t overlap,
+                            uint32_t* stage_state, float* loss_terms, float* dZ, float* dparams, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* Backward for an arbitrary upstream gradient dout[B,P,3] (generic autograd use of
  * model(Z,D)); the forward is recomputed inside the same fused kernel. */

@@ -4,5 +4,5 @@
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 D=gpurun_out/_tl_$$
 rocprofv3 --kernel-trace --stats -d $D -o k -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-also > $D.log 2>&1
-python3 profiles/timeline_rocpd.py $D/k_results.db 2>/dev/null | head -15 | cut -c1-110
+python3 profiles/timeline_rocpd.py $D/k_results.db 2>/dev/null | head -15 | cut -c1-110 | grep -v "^$"
 rm -rf $D $D.log

@@ -25,7 +25,7 @@ COND_CONCAT, COND_FILM = 0, 1
 EXPORTS = (
     "reni_last_error", "reni_plan_create", "reni_plan_destroy", "reni_param_count", "reni_in_features",
     "reni_workspace_bytes", "reni_forward", "reni_forward_loss_backward", "reni_backward",
-    "reni_forward_loss_backward_rows", "reni_train_step_rows", "reni_latent_step_rows", "reni_adam_step", "reni_adam_rows_step", "reni_adam_step2", "reni_selftest_layouts", "reni_launch_info", "reni_path_info", "reni_launch_count", "reni_set_grad_ready_event", "reni_profile_enable", "reni_profile_read", "reni_profile_read_kind", "reni_probe_tr",
+    "reni_forward_loss_backward_rows", "reni_train_step_rows", "reni_train_step_rows_dp", "reni_latent_step_rows", "reni_adam_step", "reni_adam_rows_step", "reni_adam_step2", "reni_selftest_layouts", "reni_launch_info", "reni_path_info", "reni_launch_count", "reni_set_grad_ready_event", "reni_profile_enable", "reni_profile_read", "reni_profile_read_kind", "reni_probe_tr",
     "reni_film_forward", "reni_film_forward_loss_backward", "reni_film_backward",
     "reni_film_map_param_count", "reni_film_model_forward", "reni_film_model_forward_loss_backward",
     "reni_film_model_backward",
@@ -91,6 +91,11 @@ def load():
         c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int64, c_float,
         POINTER(c_uint32), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.reni_train_step_rows.restype = c_int32
+    lib.reni_train_step_rows_dp.argtypes = [
+        c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, i64x3, c_void_p, i64x3,
+        c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int64, c_float,
+        c_void_p, c_int32, POINTER(c_uint32), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.reni_train_step_rows_dp.restype = c_int32
     lib.reni_latent_step_rows.argtypes = [
         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, i64x3, c_void_p, i64x3,
         c_int32, c_float, c_float, c_uint32, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int64,

@@ -60,6 +60,12 @@ class TrainEngine:
         self.v_lat = torch.zeros_like(self.latent.data)
         self.t = 0
         self.world = rdist.world_size()
+        if (overlap_comm or comm is not None) and not self.flat.is_cuda:  # (fail HERE, not inside torch.cuda.Stream or RCCL)
+            raise _lib.RENILibraryError("TrainEngine(comm= / overlap_comm=) needs the model on a GPU device; there is no CPU fallback")
+        # the fused data-parallel step exchanges inside the library: overlap_comm then means its early slice on the library's stream
+        self.overlap_dp = bool(overlap_comm and comm is not None and fused_step)
+        if self.overlap_dp:
+            self.overlap_comm = False
         if self.overlap_comm and not self.film and self.train_decoder:
             dev = self.flat.device
             self._comm_stream = torch.cuda.Stream(dev)
@@ -94,7 +100,10 @@ class TrainEngine:
         next_idx: the NEXT step's idx, if the caller knows it (a loader that is one batch ahead does): the fused step stages that
         batch's prologue behind this step's backward pass; the next call must then be made with exactly that idx (checked here).
         Returns the device tensor (loss, mse, prior, cosine) of this rank's batch."""
-        if (self.fused_step and not self.film and self.train_decoder and self.world == 1 and self.comm is None
+        # the fused step: one process, or -- with the library's own communicator (comm=RcclComm()) -- one rank of a data-parallel job:
+        # the SAME call with the exchange inside it (reni_train_step_rows_dp).  torch.distributed's collective cannot be put inside a
+        # library call: comm=None at world > 1 keeps the three-call path below.
+        if (self.fused_step and not self.film and self.train_decoder and (self.comm is not None or self.world == 1)
                 and hasattr(self.plan, "train_step")):
             import ctypes
             if self._stage is None:
@@ -108,9 +117,18 @@ class TrainEngine:
             self.t += 1
             _roctx.push("reni.step.fused")
             nxt = next_idx.contiguous() if next_idx is not None and int(next_idx.numel()) == shape[0] else None
+            timed = self._comm_ev is not None and self.comm is not None
+            if timed:  # (the exchange is inside the call: what is bracketed here is the whole step)
+                cur = torch.cuda.current_stream(self.flat.device)
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(cur)
             terms, _, _ = self.plan.train_step(self.latent.data, idx.contiguous(), directions, self.flat, target, weight, self.m_dec,
                                                self.v_dec, self.m_lat, self.v_lat, self.t, self.lr, st["state"], idx_next=nxt,
-                                               loss_kind=self.loss_kind, alpha=self.alpha, beta=self.beta)
+                                               loss_kind=self.loss_kind, alpha=self.alpha, beta=self.beta,
+                                               grad_scale=1.0 / self.world, comm=self.comm, overlap=self.overlap_dp)
+            if timed:
+                eb.record(cur)
+                self._comm_ev.append((ea, eb))
             st["expect"], st["shape"] = ((nxt.data_ptr(), nxt.numel()) if nxt is not None else None), shape
             _roctx.pop()
             return terms

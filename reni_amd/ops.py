@@ -74,6 +74,11 @@ class Plan:
         if ws is None or ws.numel() < n:
             ws = torch.empty(n + 256, dtype=torch.uint8, device=device)
             self._ws[key] = ws
+        # Every hand-out counts: reni_train_step_rows keeps the NEXT batch's prologue (gathered rows, A_b, layer-0 operands, packed
+        # weight images) in this buffer between two calls, and any other call on the plan -- a validation forward at another B, a
+        # fused loss, a reallocation for a larger problem -- overwrites it at shifted offsets or abandons the buffer.  train_step
+        # compares this counter with the one it saw at the end of the step that staged.
+        self._ws_gen = getattr(self, "_ws_gen", 0) + 1
         return ws
 
     @staticmethod
@@ -187,11 +192,13 @@ class Plan:
         return loss_terms, dZ, dparams, out
 
     def train_step(self, Z_table, idx, D, params, target, weight, m_dec, v_dec, m_lat, v_lat, step, lr, stage_state, idx_next=None,
-                   loss_kind="mse", alpha=0.0, beta=0.0, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+                   loss_kind="mse", alpha=0.0, beta=0.0, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, comm=None, overlap=False):
         """reni_train_step_rows: fused fwd + loss + bwd on the rows `idx` of the latent TABLE, then torch.optim.Adam's update of
         `params` and of the whole table, IN PLACE -- the same results as forward_loss_backward(idx=...) + adam_step2, with Adam and
         the next batch's prologue (`idx_next`) scheduled beside the backward pass's last kernel.  stage_state: a ctypes.c_uint32
         the caller keeps between calls (zero it whenever params / the table / the shapes change behind the library's back).
+        comm: a ``dist.RcclComm`` -- the data-parallel step (reni_train_step_rows_dp): the decoder gradient is summed over the
+        communicator's ranks INSIDE the call (pass grad_scale = 1 / world); overlap: the early slice on the library's own stream.
         Returns (loss_terms[4], dZ [B,ND,3], dparams)."""
         _require_cuda(Z_table, D, params, target, weight, idx, idx_next, m_dec, v_dec, m_lat, v_lat)
         for t in (Z_table, params, m_dec, v_dec, m_lat, v_lat):
@@ -210,15 +217,24 @@ class Plan:
         loss_terms = torch.empty(4, dtype=torch.float32, device=dev)
         dZ = torch.empty(B, self.ndims, 3, dtype=torch.float32, device=dev)
         dparams = torch.empty(self.n_params, dtype=torch.float32, device=dev)
+        # a staged prologue is only good if NOTHING took the plan's workspace since the call that staged it (see workspace())
+        if stage_state.value & 1 and getattr(self, "_stage_gen", None) != (getattr(self, "_ws_gen", 0), dev.index):
+            stage_state.value = 0
         ws = self.workspace(B, P, _lib.NEED_DW | _lib.NEED_DZ, dev)
+        self._stage_gen = (self._ws_gen, dev.index)
         wp, wn = self._aligned_ptr(ws)
         kind = {"mse": _lib.LOSS_MSE, "test": _lib.LOSS_TEST}[loss_kind]
-        _lib.check(self.lib.reni_train_step_rows(
-            self._h, B, P, Z_table.data_ptr(), Z_table.shape[0], idx.data_ptr(), idx_next.data_ptr() if idx_next is not None else None,
-            Dc.data_ptr(), dbs, params.data_ptr(), target.data_ptr(), ts, weight.data_ptr(), wst, kind, float(alpha), float(beta),
-            m_dec.data_ptr(), v_dec.data_ptr(), m_lat.data_ptr(), v_lat.data_ptr(), float(lr), float(betas[0]), float(betas[1]),
-            float(eps), int(step), float(grad_scale), ctypes.byref(stage_state), loss_terms.data_ptr(), dZ.data_ptr(),
-            dparams.data_ptr(), wp, wn, torch.cuda.current_stream(dev).cuda_stream))
+        head = (self._h, B, P, Z_table.data_ptr(), Z_table.shape[0], idx.data_ptr(), idx_next.data_ptr() if idx_next is not None else None,
+                Dc.data_ptr(), dbs, params.data_ptr(), target.data_ptr(), ts, weight.data_ptr(), wst, kind, float(alpha), float(beta),
+                m_dec.data_ptr(), v_dec.data_ptr(), m_lat.data_ptr(), v_lat.data_ptr(), float(lr), float(betas[0]), float(betas[1]),
+                float(eps), int(step), float(grad_scale))
+        tail = (ctypes.byref(stage_state), loss_terms.data_ptr(), dZ.data_ptr(), dparams.data_ptr(), wp, wn,
+                torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            if comm is not None:
+                _lib.check(self.lib.reni_train_step_rows_dp(*head, comm._comm, 1 if overlap else 0, *tail))
+            else:
+                _lib.check(self.lib.reni_train_step_rows(*head, *tail))
         return loss_terms, dZ, dparams
 
     def latent_step(self, Z_table, idx, D, params, target, weight, m_lat, v_lat, step, lr, loss_kind="test", alpha=0.0, beta=0.0,

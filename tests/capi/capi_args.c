@@ -161,6 +161,16 @@ int main(void) {
     EXPECT(reni_train_step_rows(p, 2, 256, fake, 10, (const int64_t*)fake, (const int64_t*)fake, fake, 0, fake, fake, st3(st), fake, st3(st),
                                 RENI_LOSS_MSE, 0.f, 0.f, fake, fake, fake, fake, 1e-3f, .9f, .999f, 1e-8f, 1, 1.f, &st, terms, fake, fake,
                                 ws, 16, NULL), RENI_EWORKSPACE); }
+  { uint32_t st = 0;  /* reni_train_step_rows_dp: a NULL communicator, then the same argument checks as the one-process step */
+    EXPECT(reni_train_step_rows_dp(p, 2, 256, fake, 10, (const int64_t*)fake, NULL, fake, 0, fake, fake, st3(st), fake, st3(st), RENI_LOSS_MSE,
+                                   0.f, 0.f, fake, fake, fake, fake, 1e-3f, .9f, .999f, 1e-8f, 1, .5f, NULL, 0, &st, terms, fake, fake, ws, 16,
+                                   NULL), RENI_EINVAL);
+    EXPECT(reni_train_step_rows_dp(p, 2, 256, fake, 10, NULL, NULL, fake, 0, fake, fake, st3(st), fake, st3(st), RENI_LOSS_MSE, 0.f, 0.f, fake,
+                                   fake, fake, fake, 1e-3f, .9f, .999f, 1e-8f, 1, .5f, fake, 0, &st, terms, fake, fake, ws, 16, NULL),
+           RENI_EINVAL);
+    EXPECT(reni_train_step_rows_dp(p, 2, 256, fake, 10, (const int64_t*)fake, NULL, fake, 0, fake, fake, st3(st), fake, st3(st), RENI_LOSS_MSE,
+                                   0.f, 0.f, fake, fake, fake, fake, 1e-3f, .9f, .999f, 1e-8f, 1, .5f, fake, 1, &st, terms, fake, fake, ws, 16,
+                                   NULL), RENI_EWORKSPACE); }
   /* reni_latent_step_rows: NULL idx / optimiser state, step 0, flags other than the RENI_WEIGHT_* bits, then the workspace check */
   EXPECT(reni_latent_step_rows(p, 2, 256, fake, 10, NULL, fake, 0, fake, fake, st, fake, st, RENI_LOSS_TEST, 1e-7f, 1e-4f, 0, fake, fake,
                                1e-1f, .9f, .999f, 1e-8f, 1, terms, fake, ws, 16, NULL), RENI_EINVAL);

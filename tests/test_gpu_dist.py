@@ -225,7 +225,7 @@ def test_bench_default_line_carries_every_baseline_config_and_the_capi_exchange(
     assert line["roofline"]["flop_per_sample"] == 522784 and "also" not in line["also"]["c4"]
     # ONE definition of the headline: the contract's W + K window, first; the sustained-clock re-run is a side field
     assert line["steps"] == 3 and line["warmup"] == 1 and line["sustained"]["steps"] == 3 and "from_idle" not in line
-    assert line["config"]["paths"]["dw1_kernel"] == "k_reni_dw1_ring" and line["config"]["paths"]["env_overrides"] == []
+    assert line["config"]["paths"]["dw1_kernel"] == "k_reni_l0_ring" and line["config"]["paths"]["env_overrides"] == []
     assert line["launches_per_step"] == int(line["launches_per_step"]) and 2 <= line["launches_per_step"] <= 16
     forced = _run_bench({"RENI_DW1_OLD": "1"}, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-also")
     assert forced["config"]["paths"]["dw1_kernel"] == "k_reni_dw1" and forced["config"]["paths"]["env_overrides"] == ["RENI_DW1_OLD"]
@@ -301,6 +301,93 @@ def test_rccl_comm_of_one_rank_runs_the_exchange_step():
     bit-for-bit the decoder and latents of the fused single-process update."""
     (rank, out, rows), = _spawn_rccl(1)
     assert (out[True][0] == out[False][0]).all() and (out[True][1] == out[False][1]).all()
+
+
+def _dp_step_worker(rank, world, port, q, cfg):
+    """reni_train_step_rows_dp through TrainEngine(comm=RcclComm()): every variant of the step on the same data."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        os.environ.pop("RENI_SHARE_GPU", None)
+        os.environ.pop("RENI_DIST_BACKEND", None)
+        from reni_amd import dist as rdist
+        from reni_amd.engine import TrainEngine
+        from reni_amd.models import RENIAutoDecoder
+        from reni_amd.utils import get_directions, get_sineweight
+        rdist.init_from_env()
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        comm = rdist.RcclComm(rank, world)
+        dtype, H, L, W, B = cfg
+        N = 3 * B
+        D, S = get_directions(W).to(dev), get_sineweight(W).to(dev)
+        T = torch.stack([torch.rand(D.shape[1], 3, generator=torch.Generator().manual_seed(300 + 7 * rank + i)) * 2 - 1 for i in range(N)]).to(dev)
+        batches = [torch.arange(B, device=dev) + o for o in (0, B, 2 * B, B)]
+        out = {}
+        variants = {"one_process": dict(), "dp": dict(comm=comm), "dp_overlap": dict(comm=comm, overlap_comm=True),
+                    "three_calls": dict(comm=comm, fused_step=False)}
+        if world > 1:
+            variants.pop("one_process")
+        for name, kw in variants.items():
+            torch.manual_seed(0)
+            m = RENIAutoDecoder(N, 9, "SO2", H, L, 3, True, "tanh", 30.0, 30.0, False)
+            m.set_compute_dtype(dtype).to(dev)
+            e = TrainEngine(m, lr=1e-3, **kw)
+            terms = []
+            for k, idx in enumerate(batches):
+                nxt = batches[k + 1] if k + 1 < len(batches) else None
+                terms.append(e.step(idx, T[idx], S, D, next_idx=nxt).clone())
+            torch.cuda.synchronize()
+            out[name] = [t.detach().cpu().numpy() for t in (torch.stack(terms), m._flat_params(), m.Z.data, e.m_dec, e.v_dec, e.m_lat, e.v_lat)]  # (numpy: plain pickles)
+            out[name + ".fused"] = e._stage is not None
+        comm.close()
+        q.put((rank, out, None))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc(), None))
+
+
+def _spawn_dp(world, cfg):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_step_worker, args=(r, world, port, q, cfg)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert not isinstance(r[1], str), r[1]
+    return res
+
+
+@pytest.mark.parametrize("cfg", [("bf16", 128, 5, 128, 8), ("bf16", 128, 5, 32, 4), ("f32", 64, 3, 32, 4), ("bf16", 128, 4, 64, 4)])
+def test_the_data_parallel_step_is_the_same_step(cfg):
+    """reni_train_step_rows_dp -- the fused training step with the RCCL exchange INSIDE the call -- with a one-rank
+    communicator is bit-equal to reni_train_step_rows (loss terms of every step, parameters, latents, all four Adam moments), with and
+    without the early slice on the library's stream, and equal to the three-call path (forward_loss_backward_rows -> reni_allreduce_grads
+    -> adam_step2) it replaces for comm= engines.  Paths: persistent + k_reni_l0_ring with the forked / one-stream tail, generic fp32,
+    persistent round-4 kernels (even L)."""
+    (rank, out, _), = _spawn_dp(1, cfg)
+    assert out["one_process.fused"] and out["dp.fused"] and out["dp_overlap.fused"] and not out["three_calls.fused"]
+    names = ("terms", "params", "Z", "m_dec", "v_dec", "m_lat", "v_lat")
+    for var in ("dp", "dp_overlap", "three_calls"):
+        for a, b, name in zip(out["one_process"], out[var], names):
+            assert (a == b).all(), (var, name, float(abs(a - b).max()))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")
+def test_the_data_parallel_step_on_two_gpus():
+    """Two GPUs, config 3's step: both ranks end with the same decoder; the fused DP step, its overlapped form and the three-call
+    path agree to the order of RCCL's sums (bit-equal between the two fused forms: the same collective split)."""
+    res = _spawn_dp(2, ("bf16", 128, 5, 128, 8))
+    for var in ("dp", "dp_overlap", "three_calls"):
+        assert (res[0][1][var][1] == res[1][1][var][1]).all(), var      # the replicas stay replicas
+    p_dp, p_3 = res[0][1]["dp"][1], res[0][1]["three_calls"][1]
+    assert float(abs(p_dp - p_3).max()) <= 1e-5 * float(abs(p_3).max())
+    assert float(abs(res[0][1]["dp_overlap"][1] - p_dp).max()) <= 1e-5 * float(abs(p_dp).max())
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")

@@ -55,25 +55,60 @@ def test_fused_step_is_bit_equal_to_the_two_calls(dtype, H, L, W, B, announce):
         assert torch.equal(a, b), (name, float((a - b).abs().max()))
 
 
-def test_a_batch_other_than_the_staged_one_poisons_the_step():
+@pytest.mark.parametrize("dtype,H,L", [("bf16", 128, 5), ("f32", 64, 3), ("bf16", 256, 2), ("bf16", 128, 4)])
+def test_a_batch_other_than_the_staged_one_skips_the_step_loudly(dtype, H, L):
     """The library compares the batch a staged prologue was run for with the batch the next call brings, on the device: a mismatch
-    the host-side identity check cannot see (same tensor, other contents) yields NaN, not a silently wrong step."""
+    the host-side identity check cannot see (same tensor, other contents) yields a NaN loss and NaN latent gradients AND leaves
+    parameters, latent table and Adam moments exactly as they were -- on every path (persistent + k_reni_l0_ring, persistent round-4
+    kernels (even L), generic fp32, H = 256): the step is skipped, not applied with garbage."""
     dev = torch.device("cuda:0")
     B, N = 4, 12
     D, S, T = _data(N, 64, dev)
-    m, e = _engine("bf16", 128, 5, N, True)
+    m, e = _engine(dtype, H, L, N, True)
     idx = torch.arange(B, device=dev)
     nxt = torch.arange(B, device=dev) + B
     e.step(idx, T[idx], S, D, next_idx=nxt)
+    before = _state(m, e)
     nxt[1] = 11                                  # the announced batch is changed in place behind the engine's back
     t = e.step(nxt, T[nxt], S, D)
-    assert bool(torch.isnan(t[0]))
+    assert bool(torch.isnan(t).all())
+    for a, b, name in zip(before, _state(m, e), ("params", "Z", "m_dec", "v_dec", "m_lat", "v_lat")):
+        assert torch.equal(a, b), name           # nothing moved, nothing is NaN
+    t3 = e.step(idx, T[idx], S, D)               # and the engine carries on (its own prologue: nothing was announced)
+    assert bool(torch.isfinite(t3).all())
     # announcing nothing, or another tensor: the call simply runs its own prologue
-    m2, e2 = _engine("bf16", 128, 5, N, True)
+    m2, e2 = _engine(dtype, H, L, N, True)
     e2.step(idx, T[idx], S, D, next_idx=nxt)
     other = torch.tensor([2, 5, 7, 9], device=dev)
     t2 = e2.step(other, T[other], S, D)
     assert bool(torch.isfinite(t2).all())
+
+
+@pytest.mark.parametrize("dtype,H,L,W", [("bf16", 128, 5, 64), ("f32", 64, 3, 32)])
+def test_another_call_on_the_plan_between_two_announced_steps_drops_the_stage(dtype, H, L, W):
+    """The staged prologue lives in the plan's workspace: a validation forward at another batch size, a fused loss, anything that takes
+    the workspace between two announced steps overwrites or abandons it.  The plan counts workspace hand-outs and train_step drops the
+    stage when the count moved: the interleaved run is bit-equal to the un-fused engine's."""
+    dev = torch.device("cuda:0")
+    B = 4
+    N = 3 * B
+    D, S, T = _data(N, W, dev)
+    batches = [torch.arange(B, device=dev) + o for o in (0, B, 2 * B, 0)]
+    res = {}
+    for fused in (False, True):
+        m, e = _engine(dtype, H, L, N, fused)
+        terms = []
+        for k, idx in enumerate(batches):
+            nxt = batches[k + 1] if k + 1 < len(batches) else None
+            terms.append(e.step(idx, T[idx], S, D, next_idx=nxt).clone())
+            with torch.no_grad():                # a validation forward of 7 images on the same plan, between the announced steps
+                out = m(m.Z.data[:7], D.expand(7, -1, -1)) if k != 1 else m(m.Z.data[:2], D.expand(2, -1, -1))
+            assert bool(torch.isfinite(out).all())
+        torch.cuda.synchronize()
+        res[fused] = (torch.stack(terms), _state(m, e))
+    assert torch.equal(res[False][0], res[True][0]), (res[False][0], res[True][0])
+    for a, b, name in zip(res[False][1], res[True][1], ("params", "Z", "m_dec", "v_dec", "m_lat", "v_lat")):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
 
 
 @pytest.mark.parametrize("dtype,H,L,W,sparse", [
