@@ -56,3 +56,32 @@ def test_l0x_split_against_the_oracle_and_round_4s_kernels(dev, B, gw, P):
     gp = unflatten(spec, dp.cpu())
     for k in gp:  # (the first layer -- through dA -- and layer 1 are the two pieces k_reni_l0_ring owns)
         assert O.rel_l2(gp[k].numpy(), ref["grads"][k]) <= 3e-2, (k, O.rel_l2(gp[k].numpy(), ref["grads"][k]))
+
+
+def test_l0x_rows_by_lds_dma_in_both_layouts(dev):
+    """The L0X instance fetches a tile's target / weight rows by LDS-DMA: [P][3] interleaved rows and the channel-planar view
+    RENI.training_step passes (`imgs.permute(0, 2, 3, 1).view(B, -1, 3)` of a [B, 3, H, W] batch, RENI_module.py:83-84) give the
+    same bits; a layout it cannot fetch (rows not 16-byte aligned) takes round 4's kernels and agrees to the bf16 tolerance."""
+    spec = O.DecoderSpec(36, "SO2", 128, 5, 3, True, "tanh")
+    B = 5
+    params, Z, D, W, T = random_problem(spec, B, 0, seed=77, grid_w=128)
+    plan = make_plan(spec, "bf16")
+    fp = flat_params(spec, params).to(dev)
+    Zd, Dd = Z.to(dev), D.to(dev)
+    Ti, Wi = T.to(dev), W.expand(B, -1, 3).contiguous().to(dev)                 # interleaved [B, P, 3]
+    Tp = Ti.permute(0, 2, 1).contiguous().permute(0, 2, 1)                       # planar: strides (3 P, 1, P)
+    Wp = Wi.permute(0, 2, 1).contiguous().permute(0, 2, 1)
+    assert Tp.stride() == (3 * T.shape[1], 1, T.shape[1]) and torch.equal(Tp, Ti)
+    r_i = [t.clone() for t in plan.forward_loss_backward(Zd, Dd, fp, Ti, Wi)[:3]]
+    r_p = [t.clone() for t in plan.forward_loss_backward(Zd, Dd, fp, Tp, Wp)[:3]]
+    r_m = [t.clone() for t in plan.forward_loss_backward(Zd, Dd, fp, Tp, Wi)[:3]]
+    for a, b, c in zip(r_i, r_p, r_m):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    # an unaligned view: one float of padding in front of every image
+    pad = torch.zeros(B, T.shape[1] * 3 + 1, device=dev)
+    pad[:, 1:] = Ti.reshape(B, -1)
+    Tu = pad[:, 1:].view(B, -1, 3)
+    assert Tu.data_ptr() % 16 != 0
+    r_u = plan.forward_loss_backward(Zd, Dd, fp, Tu, Wi)[:3]
+    assert abs(float(r_u[0][0]) - float(r_i[0][0])) <= 1e-6 * abs(float(r_i[0][0]))
+    assert O.rel_l2(r_u[1].cpu().numpy(), r_i[1].cpu().numpy()) <= 2e-3 and O.rel_l2(r_u[2].cpu().numpy(), r_i[2].cpu().numpy()) <= 2e-3
