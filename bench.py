@@ -234,7 +234,7 @@ def mask3(sidelen):
 
 
 def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None, defer=False, res=None, hidden=128, eq="SO2", dense=False,
-               pixels=False):
+               pixels=False, force_dtype=None):
     """One bench configuration in this process: build the model / engine, warm up, time `steps` steps between barriers.
     Returns the record (value, ms_per_step, roofline ...) on every rank; timing is the MAX over ranks.
     res = (height, width) of the c2 step's images (the multi-resolution curriculum), hidden = the SIREN's width."""
@@ -248,7 +248,7 @@ def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None,
     torch.cuda.empty_cache()  # (what the previous configuration of this process left in the caching allocator)
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
-    dtype = args.dtype or ("f32" if cfg == "c5" else "bf16")
+    dtype = force_dtype or args.dtype or ("f32" if cfg == "c5" else "bf16")
     torch.manual_seed(42)
     if cfg == "c2":
         N_IMAGES, (H_IMG, W_IMG), ND, B = 615, res or (128, 256), 36, batch or 64
@@ -366,6 +366,8 @@ def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, 
     launches = ops.launch_count(reset=True)
     kind = ops.PROF_FWD if cfg == "c5" else ops.PROF_FWD_BWD
     kern_ms, kern_n = ops.profile_read(reset=False, kind=kind)
+    kern_min, kern_max = ops.profile_minmax(kind)
+    dw1_ms, dw1_n = ops.profile_read(reset=False, kind=ops.PROF_DW1)
     stats_ms, stats_n = ops.profile_read(reset=True, kind=ops.PROF_STATS)
     ops.profile_enable(False)
     comm_us = eng.time_comm(False) if eng is not None else None
@@ -383,7 +385,9 @@ def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, 
     if cfg == "c2":
         flop = flop_train(shape["ND"], H, 5)
         assert H != 128 or flop == FLOP_TRAIN
-        kernel = (f"k_reni_train_bf16<128,true>" if (dtype == "bf16" and H == 128) else f"k_reni_main<{dtype},H={H},FWD_BWD>")
+        l0x = isinstance(paths, dict) and paths.get("dw1_kernel") == "k_reni_l0_ring"   # (round 5: the L0X instance + k_reni_l0_ring)
+        kernel = (("k_reni_train_bf16<128,true,L0X>" if l0x else "k_reni_train_bf16<128,true>") if (dtype == "bf16" and H == 128)
+                  else f"k_reni_main<{dtype},H={H},FWD_BWD>")
         workload = (f"BASELINE config 2: 615-image set, {shape['res'][0]}x{shape['res'][1]} equirect, ND=36, 5x{H} SIREN, SO2, tanh, "
                     "AutoDecoder, RENITrainLoss; full training step (fwd+loss+bwd, grad all-reduce, Adam)")
     elif cfg == "film":
@@ -409,9 +413,29 @@ def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, 
     visited = shape["sparsity"]["tiles_visited"] if shape.get("sparsity") else 1.0
     achieved = visited * B * P * steps * flop / (max(kern_ms, 1e-9) * 1e-3) / 1e12
     pmc = pmc_record(kernel)
+    # Three fractions of the same peak, so that moving FLOPs between kernels cannot improve the number by relabelling:
+    #   frac        SURVEY 8(d)'s yardstick: ALL algorithmic FLOPs of the step over the DOMINANT kernel's run time
+    #   frac_step   the same FLOPs over the whole step's wall time (every kernel, every gap)
+    #   frac_issued per kernel: the MFMA FLOPs it actually issues (SQ_INSTS_MFMA of the PMC passes x FLOP per instruction) over its own
+    #               HIP-event time -- `kernels` lists the training kernel and the kernel that finishes the backward pass behind it
+    step_flops = visited * B * P * steps * flop
+    mfma_flop = 32768.0 if dtype == "bf16" else 4096.0   # v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32
     roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-            "frac": achieved / PEAK_TFLOPS[dtype], "traffic": pmc.get("hbm_bytes_per_launch"), "kernel": kernel,
-            "kernel_avg_ms": kavg_ms, "kernel_launches": kern_n, "flop_per_sample": flop}
+            "frac": achieved / PEAK_TFLOPS[dtype], "frac_step": step_flops / dt / 1e12 / PEAK_TFLOPS[dtype],
+            "frac_issued": (pmc["mfma_per_launch"] * mfma_flop / (kavg_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype])
+            if pmc.get("mfma_per_launch") and kavg_ms > 0 else None,
+            "traffic": pmc.get("hbm_bytes_per_launch"), "kernel": kernel,
+            "kernel_avg_ms": kavg_ms, "kernel_min_ms": kern_min, "kernel_max_ms": kern_max, "kernel_launches": kern_n,
+            "flop_per_sample": flop}
+    if dw1_n:
+        k2 = paths.get("dw1_kernel", "k_reni_dw1") if isinstance(paths, dict) else "k_reni_dw1"
+        p2 = pmc_record(k2)
+        a2 = dw1_ms / dw1_n
+        roof["kernels"] = [
+            {"kernel": kernel, "avg_ms": kavg_ms, "frac_issued": roof["frac_issued"], "traffic": pmc.get("hbm_bytes_per_launch")},
+            {"kernel": k2, "avg_ms": a2, "launches": dw1_n, "traffic": p2.get("hbm_bytes_per_launch"),
+             "frac_issued": (p2["mfma_per_launch"] * mfma_flop / (a2 * 1e-3) / 1e12 / PEAK_TFLOPS[dtype]) if p2.get("mfma_per_launch") else None,
+             "hbm_frac": (p2["hbm_bytes_per_launch"] / (a2 * 1e-3) / 8e12) if p2.get("hbm_bytes_per_launch") else None}]
     if pmc.get("valu_per_mfma"):
         # the co-bound: one wave per SIMD issues the SIREN's activation / epilogue VALU through the same port as its
         # MFMAs; `issue_limited_frac` is the MFMA-peak fraction that instruction mix allows even with perfect overlap
@@ -459,6 +483,8 @@ def sub_record(name, args, rank, world, dev):
         m = run_config("c4", args, rank, world, dev, dense=True, **kw)
     elif name == "c4_pixels":  # config 4 with RENI_WEIGHT_COMPACT: the pixels with weight packed into each image's first tiles
         m = run_config("c4", args, rank, world, dev, pixels=True, **kw)
+    elif name == "c4_f32":    # config 4 on the fp32 (parity-grade) kernels, RENI_WEIGHT_SPARSE: the arithmetic to use when the LATENTS, not
+        m = run_config("c4", args, rank, world, dev, force_dtype="f32", **kw)   # only the loss curve, must track the reference
     elif name == "c2_h256":   # the width of the reference's shipped configs (configs/default.py:13)
         m = run_config("c2", args, rank, world, dev, hidden=256, **kw)
     else:
@@ -470,13 +496,20 @@ def sub_record(name, args, rank, world, dev):
     r = min(wins, key=lambda x: x["ms_per_step"])
     out = {"metric": METRIC_FWD if name == "c5" else METRIC_TRAIN.replace("128x256", "%dx%d" % tuple(int(x) for x in name[10:].split("x")))
            if name.startswith("c2_curric_") else METRIC_TRAIN,
-           "value": r["value"] / (world if name in ("c4", "c4_dense", "c4_pixels", "c5") else 1), "unit": "samples/s",
+           "value": r["value"] / (world if name in ("c4", "c4_dense", "c4_pixels", "c4_f32", "c5") else 1), "unit": "samples/s",
            "ms_per_step": r["ms_per_step"], "ms_per_step_windows": [w_["ms_per_step"] for w_ in wins],
+           "ms_per_step_mean": sum(w_["ms_per_step"] for w_ in wins) / len(wins),   # (not only the faster window)
            "steps": r["steps"], "launches_per_step": r["launches_per_step"],
            "dtype": r["dtype"], "workload": r["config"]["workload"],
            "images_per_gpu_per_step": r["config"]["images_per_gpu_per_step"], "paths": r["config"]["paths"], "roofline": r["roofline"]}
     if "weight_sparsity" in r["config"]:
         out["weight_sparsity"] = r["config"]["weight_sparsity"]
+        # with RENI_WEIGHT_SPARSE / _COMPACT `value` counts EVERY direction of the images -- what the reference evaluates for the same
+        # result -- although the kernels visit only the tiles that can change it: label it, and print what was visited beside it.
+        # The figure to compare with BASELINE config 4 and with rounds 1-3 is `c4_dense`.
+        vis = r["config"]["weight_sparsity"]["tiles_visited"]
+        out["value_kind"] = "effective_samples_per_s" if vis < 1.0 else "samples_per_s"
+        out["visited_samples_per_s"] = out["value"] * vis
     if name == "c5":  # SURVEY 8(d) C5 names both invariances: the SO3 model through the same kernel
         r3 = run_config("c5", args, rank, world, dev, eq="SO3", **kw)()
         out["so3"] = {"value": r3["value"] / world, "ms_per_step": r3["ms_per_step"], "frac": r3["roofline"]["frac"],
@@ -523,7 +556,7 @@ def main():
         # configurations whose ranks are independent (c4, c5: rank 0's own replica).
         also = {}
         user_dtype = args.dtype
-        names = (("c4", "c4_dense", "c4_pixels", "c5", "film", "c2_b100") + tuple(f"c2_curric_{h}x{w}" for h, w in CURRIC) + ("c2_h256",)) if world == 1 else ("c4", "c5")
+        names = (("c4", "c4_dense", "c4_pixels", "c4_f32", "c5", "film", "c2_b100") + tuple(f"c2_curric_{h}x{w}" for h, w in CURRIC) + ("c2_h256",)) if world == 1 else ("c4", "c5")
         for c in names:
             args.dtype = None
             try:

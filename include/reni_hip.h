@@ -73,6 +73,10 @@ extern "C" {
  * tiles -- packed, in 49.  The same terms are then summed in another order: results equal the dense ones to fp32 rounding, not bit
  * for bit (run-to-run they stay bit-identical). */
 #define RENI_WEIGHT_COMPACT 8u
+/* reni_latent_step_rows_cached only: the lists' build reported no image with a live cosine term (summary[2] == 0: pixel 0 of every
+ * image is masked, as in every mask of the reference's data/Masks) -- the statistics pass and its per-image kernel, which would visit
+ * nothing and write zero coefficients, are not launched.  Same results, two launches fewer. */
+#define RENI_WEIGHT_COS_CONSTANT 16u
 
 typedef struct reni_plan reni_plan;
 
@@ -273,6 +277,29 @@ int reni_latent_step_rows(const reni_plan* plan, int64_t B, int64_t P, float* Z_
                           uint32_t flags, float* m_lat, float* v_lat, float lr, float b1, float b2, float eps, int64_t step,
                           float* loss_terms, float* dZ, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The lists RENI_WEIGHT_SPARSE / RENI_WEIGHT_COMPACT work from -- which tiles carry weight, which images' cosine term is live, and
+ * (COMPACT) the position -> pixel map -- depend on the loss weight alone, and the inpainting mask of a FIT_LATENT run is constant
+ * over its 2 400 epochs (/root/reference/configs/experiment.yaml:47-48; RENI_module.py:92-94 multiplies the same mask into the sine
+ * weight every step).  reni_latent_step_rows rebuilds them from the weight in every call (two or three dependent launches and an
+ * 8 MB read in front of a 0.2 ms step); here the caller builds them ONCE into a buffer of its own and hands them to every step:
+ *   reni_weight_lists_bytes(B, P)            size of the buffer (256-byte aligned device memory);
+ *   reni_weight_lists_build(...)             fills it for this weight, these strides and `flags` (SPARSE or COMPACT), on `stream`;
+ *                                            optionally reports what the lists hold (one synchronisation);
+ *   reni_latent_step_rows_cached(..., lists) reni_latent_step_rows with the list-building launches left out: the same kernels on the
+ *                                            same lists, results BIT-EQUAL to the rebuilt-every-call entry point.
+ * The caller rebuilds the lists whenever the weight, B or P changes; `flags` of the step = `flags` of the build. */
+size_t reni_weight_lists_bytes(int64_t B, int64_t P);
+/* summary_host (optional, 3 ints): after ONE stream synchronisation -- tiles the main pass will visit, tiles of the statistics pass,
+ * images whose cosine term is live (0: the steps may carry RENI_WEIGHT_COS_CONSTANT). */
+int reni_weight_lists_build(int64_t B, int64_t P, const float* weight, const int64_t weight_strides[3], uint32_t flags, void* lists,
+                            size_t lists_bytes, int32_t* summary_host, void* stream);
+int reni_latent_step_rows_cached(const reni_plan* plan, int64_t B, int64_t P, float* Z_table, int64_t n_rows, const int64_t* idx,
+                                 const float* D, int64_t d_batch_stride, const float* params, const float* target,
+                                 const int64_t target_strides[3], const float* weight, const int64_t weight_strides[3],
+                                 int32_t loss_kind, float alpha, float beta, uint32_t flags, const void* weight_lists, float* m_lat,
+                                 float* v_lat, float lr, float b1, float b2, float eps, int64_t step, float* loss_terms, float* dZ,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same Adam step over a table p [n_rows][row_len] whose gradient is given for the B rows idx[0..B) only
  * (g_rows [B][row_len], idx int64 on the device; repeated indices accumulate).  All other rows have gradient zero and
  * still move by their momentum: the dense torch.optim.Adam over the whole latent table that the reference runs
@@ -298,8 +325,13 @@ int reni_selftest_layouts(int32_t* out_host_mismatch, int32_t n_probes);
 int reni_profile_enable(int32_t on);
 int reni_profile_read(double* total_ms, int64_t* launches, int32_t reset);
 /* The same, restricted to one kind of launch: 0 fused forward+loss+backward (what reni_profile_read returns),
- * 1 the statistics pass of RENITestLoss's cosine term, 2 plain inference (reni_forward), -1 all of them. */
+ * 1 the statistics pass of RENITestLoss's cosine term, 2 plain inference (reni_forward), 3 the kernel that finishes the
+ * backward pass from the g_1 stream behind the persistent training kernel (k_reni_l0_ring / k_reni_dw1_ring / k_reni_dw1),
+ * -1 all of them. */
 int reni_profile_read_kind(int32_t kind, double* total_ms, int64_t* launches, int32_t reset);
+/* Shortest and longest launch of one kind among those recorded since the last reset (bench.py prints them beside the average:
+ * boxes of the pool differ by several per cent, a cross-round delta is read against that spread).  Does not reset. */
+int reni_profile_minmax(int32_t kind, double* min_ms, double* max_ms);
 
 /* Diagnostic probe of the LDS transpose-read instruction (ds_read_b64_tr_b16): LDS holds u16 element i = i;
  * lane l reads at byte address 8*l (mode 0) or lane_addr_host[l] (mode 1); out_host[4*l + e] = element e. */

@@ -19,10 +19,13 @@ for path in sys.argv[1:]:
         m = re.match(r"\| `(.+?)` \| ([A-Z_0-9]+) \| (\d+) \| ([0-9.e+]+) \|", line)
         if m:
             rows.setdefault(m.group(1), {})[m.group(2)] = float(m.group(4))
-names = {"k_reni_train_bf16<128, true, false, false, true>": "k_reni_train_bf16<128,true>",   # (the SPEC instance: what config 2 runs)
-         "k_reni_train_bf16<128, false, false, false, false>": "k_reni_train_bf16<128,false>",
-         "k_reni_train_bf16<128, false, true, false, false>": "k_reni_train_bf16<128,false,true>",
-         "k_reni_train_bf16<128, true, false, true, true>": "k_reni_train_bf16<128,true,false,true>",   # (FiLM: its SPEC instance)
+names = {"k_reni_train_bf16<128, true, false, false, true, true>": "k_reni_train_bf16<128,true,L0X>",   # (SPEC + L0X: what config 2 runs, round 5)
+         "k_reni_l0_ring<128>": "k_reni_l0_ring",                                                         # (layer 0's backward + dW_1 behind it)
+         "k_reni_train_bf16<128, true, false, false, true, false>": "k_reni_train_bf16<128,true>",       # (the SPEC instance of round 4: RENI_NO_L0X)
+         "k_reni_train_bf16<128, false, false, false, false, false>": "k_reni_train_bf16<128,false>",
+         "k_reni_train_bf16<128, false, true, false, false, false>": "k_reni_train_bf16<128,false,true>",
+         "k_reni_train_bf16<128, true, false, true, true, false>": "k_reni_train_bf16<128,true,false,true>",   # (FiLM: its SPEC instance)
+         "k_reni_main<reni::PolBF16, 256, 2, false>": "k_reni_main<bf16,H=256,FWD_BWD>",                 # (c2_h256: the shipped width)
          "k_reni_main<reni::PolF32, 128, 0, false>": "k_reni_main<f32,H=128,FWD>"}
 sha = kernel_src_sha()
 out = {}
@@ -32,6 +35,8 @@ for k, v in rows.items():
             rec = {"hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), "FETCH_SIZE_KB": v["FETCH_SIZE"],
                    "WRITE_SIZE_KB": v["WRITE_SIZE"], "src_sha256": sha,
                    "note": "2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes of bench.py --steps 3; L2 <-> fabric bytes, Infinity-Cache hits included"}
+            if "SQ_INSTS_MFMA" in v:  # per launch: bench.py's frac_issued = this x FLOP per MFMA / the kernel's own time
+                rec["mfma_per_launch"] = int(v["SQ_INSTS_MFMA"])
             if "SQ_INSTS_VALU" in v and "SQ_INSTS_MFMA" in v:  # (SQ_INSTS_VALU counts the MFMAs too)
                 rec["valu_per_mfma"] = round((v["SQ_INSTS_VALU"] - v["SQ_INSTS_MFMA"]) / v["SQ_INSTS_MFMA"], 3)
                 if "SQ_INSTS_VALU_TRANS" in v:

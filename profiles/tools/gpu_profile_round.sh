@@ -6,7 +6,7 @@ TAG=$1
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
 rm -f $O/pmc_counters.md $O/pmc_instruction_mix.md
-for c in c2 c4 c5 film; do
+for c in c2 c4 c5 film c2_h256; do
   for cnt in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $cnt --kernel-trace -d $O/pmc_$cnt -o p -- python3 bench.py --config $c --steps 3 --warmup 2 --no-cpu-baseline --no-also > $O/pmc_$cnt.log 2>&1
     python3 profiles/summarize_pmc.py $O/pmc_$cnt/p_results.db >> $O/pmc_counters.md 2>&1
@@ -16,7 +16,7 @@ done
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_MFMA" "SQ_INSTS_VALU_TRANS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC" "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-60)
   timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $O/g_$tag -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also > $O/g_$tag.log 2>&1
-  python3 profiles/summarize_pmc.py $O/g_$tag/p_results.db 2>&1 | grep -i "train_bf16\|dw1\|^##\|^| kernel\|^|---" >> $O/pmc_instruction_mix.md
+  python3 profiles/summarize_pmc.py $O/g_$tag/p_results.db 2>&1 | grep -i "train_bf16\|dw1\|l0_ring\|^##\|^| kernel\|^|---" >> $O/pmc_instruction_mix.md
   rm -rf $O/g_$tag $O/g_$tag.log
 done
 python3 profiles/make_pmc_traffic.py $O/pmc_counters.md $O/pmc_instruction_mix.md > $O/pmc_traffic.json 2>> $O/bench.err

@@ -18,14 +18,14 @@ EQ = {"None": 0, None: 0, "SO2": 1, "SO3": 2}
 ACT = {None: 0, "None": 0, "none": 0, "tanh": 1, "exp": 2}
 DTYPE = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 LOSS_MSE, LOSS_TEST = 0, 1
-NEED_DW, NEED_DZ, WEIGHT_SPARSE, WEIGHT_COMPACT = 1, 2, 4, 8
+NEED_DW, NEED_DZ, WEIGHT_SPARSE, WEIGHT_COMPACT, WEIGHT_COS_CONSTANT = 1, 2, 4, 8, 16
 COND_CONCAT, COND_FILM = 0, 1
 
 # every symbol include/reni_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
     "reni_last_error", "reni_plan_create", "reni_plan_destroy", "reni_param_count", "reni_in_features",
     "reni_workspace_bytes", "reni_forward", "reni_forward_loss_backward", "reni_backward",
-    "reni_forward_loss_backward_rows", "reni_train_step_rows", "reni_train_step_rows_dp", "reni_latent_step_rows", "reni_adam_step", "reni_adam_rows_step", "reni_adam_step2", "reni_selftest_layouts", "reni_launch_info", "reni_path_info", "reni_launch_count", "reni_set_grad_ready_event", "reni_profile_enable", "reni_profile_read", "reni_profile_read_kind", "reni_probe_tr",
+    "reni_forward_loss_backward_rows", "reni_train_step_rows", "reni_train_step_rows_dp", "reni_latent_step_rows", "reni_latent_step_rows_cached", "reni_weight_lists_bytes", "reni_weight_lists_build", "reni_adam_step", "reni_adam_rows_step", "reni_adam_step2", "reni_selftest_layouts", "reni_launch_info", "reni_path_info", "reni_launch_count", "reni_set_grad_ready_event", "reni_profile_enable", "reni_profile_read", "reni_profile_read_kind", "reni_profile_minmax", "reni_probe_tr",
     "reni_film_forward", "reni_film_forward_loss_backward", "reni_film_backward",
     "reni_film_map_param_count", "reni_film_model_forward", "reni_film_model_forward_loss_backward",
     "reni_film_model_backward",
@@ -101,6 +101,15 @@ def load():
         c_int32, c_float, c_float, c_uint32, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int64,
         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.reni_latent_step_rows.restype = c_int32
+    lib.reni_latent_step_rows_cached.argtypes = [
+        c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, i64x3, c_void_p, i64x3,
+        c_int32, c_float, c_float, c_uint32, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int64,
+        c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.reni_latent_step_rows_cached.restype = c_int32
+    lib.reni_weight_lists_bytes.argtypes = [c_int64, c_int64]
+    lib.reni_weight_lists_bytes.restype = c_size_t
+    lib.reni_weight_lists_build.argtypes = [c_int64, c_int64, c_void_p, i64x3, c_uint32, c_void_p, c_size_t, POINTER(c_int32), c_void_p]
+    lib.reni_weight_lists_build.restype = c_int32
     lib.reni_adam_step2.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                     c_int64, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int64, c_float,
                                     c_void_p]
@@ -152,6 +161,8 @@ def load():
     lib.reni_profile_read.restype = c_int32
     lib.reni_profile_read_kind.argtypes = [c_int32, POINTER(ctypes.c_double), POINTER(c_int64), c_int32]
     lib.reni_profile_read_kind.restype = c_int32
+    lib.reni_profile_minmax.argtypes = [c_int32, POINTER(ctypes.c_double), POINTER(ctypes.c_double)]
+    lib.reni_profile_minmax.restype = c_int32
     lib.reni_envmap_shade_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]
     lib.reni_envmap_shade_workspace_bytes.restype = c_size_t
     for fn in (lib.reni_envmap_shade, lib.reni_envmap_shade_backward):

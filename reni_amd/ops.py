@@ -237,8 +237,31 @@ class Plan:
                 _lib.check(self.lib.reni_train_step_rows(*head, *tail))
         return loss_terms, dZ, dparams
 
+    def weight_lists(self, B, P, weight, mode):
+        """The tile / pixel lists of a masked weight (reni_weight_lists_build), built ONCE per (weight tensor, its version counter,
+        shape, strides, mode) and kept on the plan: the inpainting mask of a FIT_LATENT run does not change over its epochs.
+        weight: the [B, P, 3] (expanded) view the step passes; mode: _lib.WEIGHT_SPARSE or _lib.WEIGHT_COMPACT."""
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), tuple(weight.stride()), int(B), int(P), int(mode), weight.device.index)
+        cache = self.__dict__.setdefault("_wlists", {})
+        hit = cache.get("key") == key
+        if not hit:
+            n = int(self.lib.reni_weight_lists_bytes(B, P))
+            buf = cache.get("buf")
+            if buf is None or buf.numel() < n + 256 or buf.device != weight.device:
+                buf = torch.empty(n + 256, dtype=torch.uint8, device=weight.device)
+            lp = (buf.data_ptr() + 255) & ~255
+            wst = (ctypes.c_int64 * 3)(*weight.stride())
+            summary = (ctypes.c_int32 * 3)()
+            with torch.cuda.device(weight.device):
+                _lib.check(self.lib.reni_weight_lists_build(B, P, weight.data_ptr(), wst, int(mode), lp, buf.numel() - (lp - buf.data_ptr()),
+                                                            summary, torch.cuda.current_stream(weight.device).cuda_stream))
+            # (one synchronisation per mask: no image with a live cosine term -> the steps leave the statistics launches out)
+            cache.update(key=key, buf=buf, ptr=lp, weight=weight, cos_constant=summary[2] == 0,   # (the weight is kept alive: its
+                         summary=tuple(summary))                                                  #  data_ptr is part of the key)
+        return cache["ptr"], (_lib.WEIGHT_COS_CONSTANT if cache["cos_constant"] else 0)
+
     def latent_step(self, Z_table, idx, D, params, target, weight, m_lat, v_lat, step, lr, loss_kind="test", alpha=0.0, beta=0.0,
-                    betas=(0.9, 0.999), eps=1e-8, sparse_weight=False):
+                    betas=(0.9, 0.999), eps=1e-8, sparse_weight=False, cache_lists=True):
         """reni_latent_step_rows: one FIT_LATENT iteration (frozen decoder) -- forward_loss_backward(idx=..., need_dw=False) then
         adam_rows_step on the table, IN PLACE, as one library call.  Returns (loss_terms[4], dZ [B,ND,3])."""
         _require_cuda(Z_table, D, params, target, weight, idx, m_lat, v_lat)
@@ -263,11 +286,22 @@ class Plan:
         ws = self.workspace(B, P, _lib.NEED_DZ | flags, dev)
         wp, wn = self._aligned_ptr(ws)
         kind = {"mse": _lib.LOSS_MSE, "test": _lib.LOSS_TEST}[loss_kind]
-        _lib.check(self.lib.reni_latent_step_rows(
-            self._h, B, P, Z_table.data_ptr(), Z_table.shape[0], idx.data_ptr(), Dc.data_ptr(), dbs, params.data_ptr(),
-            target.data_ptr(), ts, weight.data_ptr(), wst, kind, float(alpha), float(beta), flags, m_lat.data_ptr(), v_lat.data_ptr(),
-            float(lr), float(betas[0]), float(betas[1]), float(eps), int(step), loss_terms.data_ptr(), dZ.data_ptr(), wp, wn,
-            torch.cuda.current_stream(dev).cuda_stream))
+        head = (self._h, B, P, Z_table.data_ptr(), Z_table.shape[0], idx.data_ptr(), Dc.data_ptr(), dbs, params.data_ptr(),
+                target.data_ptr(), ts, weight.data_ptr(), wst, kind, float(alpha), float(beta), flags)
+        tail = (m_lat.data_ptr(), v_lat.data_ptr(), float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
+                loss_terms.data_ptr(), dZ.data_ptr(), wp, wn, torch.cuda.current_stream(dev).cuda_stream)
+        chunked = False
+        if flags:  # (H = 256 problems that run in image chunks keep the rebuilding entry point; decided once per shape)
+            cc = self.__dict__.setdefault("_chunk_cache", {})
+            if (B, P) not in cc:
+                cc[(B, P)] = self.path_info(B, P, need_dw=False)["images_per_chunk"] < B
+            chunked = cc[(B, P)]
+        if flags and cache_lists and not chunked:
+            # the lists from the plan's cache (built once per mask: reni_weight_lists_build), the step without its list-building launches
+            lptr, extra = self.weight_lists(B, P, weight, flags)
+            _lib.check(self.lib.reni_latent_step_rows_cached(*head[:-1], flags | extra, lptr, *tail))
+        else:
+            _lib.check(self.lib.reni_latent_step_rows(*head, *tail))
         return loss_terms, dZ
 
     def backward(self, Z, D, params, dout, need_dw=True, need_dz=True):
@@ -499,7 +533,14 @@ def profile_enable(on: bool = True):
     _lib.check(_lib.load().reni_profile_enable(1 if on else 0))
 
 
-PROF_FWD_BWD, PROF_STATS, PROF_FWD, PROF_ALL = 0, 1, 2, -1
+PROF_FWD_BWD, PROF_STATS, PROF_FWD, PROF_DW1, PROF_ALL = 0, 1, 2, 3, -1
+
+
+def profile_minmax(kind: int = PROF_FWD_BWD):
+    """-> (shortest, longest) launch in milliseconds of one kind since the last reset (reni_profile_minmax; call before the reset)."""
+    lo, hi = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    _lib.check(_lib.load().reni_profile_minmax(int(kind), ctypes.byref(lo), ctypes.byref(hi)))
+    return lo.value, hi.value
 
 
 def profile_read(reset: bool = True, kind: int = PROF_FWD_BWD):

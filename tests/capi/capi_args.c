@@ -171,6 +171,18 @@ int main(void) {
     EXPECT(reni_train_step_rows_dp(p, 2, 256, fake, 10, (const int64_t*)fake, NULL, fake, 0, fake, fake, st3(st), fake, st3(st), RENI_LOSS_MSE,
                                    0.f, 0.f, fake, fake, fake, fake, 1e-3f, .9f, .999f, 1e-8f, 1, .5f, fake, 1, &st, terms, fake, fake, ws, 16,
                                    NULL), RENI_EWORKSPACE); }
+  /* reni_weight_lists_*: sizes, flags, alignment; reni_latent_step_rows_cached: NULL lists, flags without a RENI_WEIGHT_* mode */
+  EXPECT(reni_weight_lists_bytes(0, 256) == 0 ? RENI_OK : RENI_EINVAL, RENI_OK);
+  EXPECT(reni_weight_lists_bytes(2, 256) > 2 * 256 * 4 ? RENI_OK : RENI_EINVAL, RENI_OK);
+  EXPECT(reni_weight_lists_build(2, 256, fake, st, 0, ws, 1 << 20, NULL, NULL), RENI_EINVAL);
+  EXPECT(reni_weight_lists_build(2, 256, NULL, st, RENI_WEIGHT_SPARSE, ws, 1 << 20, NULL, NULL), RENI_EINVAL);
+  EXPECT(reni_weight_lists_build(2, 256, fake, st, RENI_WEIGHT_SPARSE, ws, 16, NULL, NULL), RENI_EWORKSPACE);
+  EXPECT(reni_latent_step_rows_cached(p, 2, 256, fake, 10, (const int64_t*)fake, fake, 0, fake, fake, st, fake, st, RENI_LOSS_TEST, 1e-7f, 1e-4f,
+                                      RENI_WEIGHT_SPARSE, NULL, fake, fake, 1e-1f, .9f, .999f, 1e-8f, 1, terms, fake, ws, 16, NULL), RENI_EINVAL);
+  EXPECT(reni_latent_step_rows_cached(p, 2, 256, fake, 10, (const int64_t*)fake, fake, 0, fake, fake, st, fake, st, RENI_LOSS_TEST, 1e-7f, 1e-4f,
+                                      0, ws, fake, fake, 1e-1f, .9f, .999f, 1e-8f, 1, terms, fake, ws, 16, NULL), RENI_EINVAL);
+  EXPECT(reni_latent_step_rows_cached(p, 2, 256, fake, 10, (const int64_t*)fake, fake, 0, fake, fake, st, fake, st, RENI_LOSS_TEST, 1e-7f, 1e-4f,
+                                      RENI_WEIGHT_COMPACT, ws, fake, fake, 1e-1f, .9f, .999f, 1e-8f, 1, terms, fake, ws, 16, NULL), RENI_EWORKSPACE);
   /* reni_latent_step_rows: NULL idx / optimiser state, step 0, flags other than the RENI_WEIGHT_* bits, then the workspace check */
   EXPECT(reni_latent_step_rows(p, 2, 256, fake, 10, NULL, fake, 0, fake, fake, st, fake, st, RENI_LOSS_TEST, 1e-7f, 1e-4f, 0, fake, fake,
                                1e-1f, .9f, .999f, 1e-8f, 1, terms, fake, ws, 16, NULL), RENI_EINVAL);

@@ -472,7 +472,9 @@ def _c2_decoder():
 def g14():
     """Config-4 re-enactment at the BENCH architecture (examples.ipynb cell 4; RENI_module.py:126-128; loss_functions.py:60-71):
     ND = 36, 5 x 128, frozen decoder, 3 maps at 64 x 128, the real Mask-3, RENITestLoss(1e-7, 1e-4), Adam(lr 1e-1) on the latents
-    from zero, 200 steps.  Recorded: the loss 4-tuple of steps 0, 10, ..., 190 and 199, the latents after 20, 100 and 200 steps."""
+    from zero, 200 steps.  Recorded: the loss 4-tuple of steps 0, 10, ..., 190 and 199, the latents after 20, 100 and 200 steps, and
+    the completed maps model(Z_after_200, D) -- the loop's product -- of the fp32 run and of the autocast-bf16 run (the latter as fp16:
+    only a PSNR is taken from it)."""
     src = _c2_decoder()
     ckpt = {"model." + k: v.clone() for k, v in src.state_dict().items()}
     N, W = 3, 128
@@ -509,10 +511,14 @@ def g14():
                 rec_at.append(it); terms.append([x.item() for x in tl])
             if it + 1 in (20, 100, 200):
                 snaps[f"Z_after_{it + 1}"] = m.Z.detach().numpy().copy()
-        return rec_at, terms, snaps
+        # the PRODUCT of the inpainting loop (examples.ipynb cell 4: `model_output = model(Z, directions)` behind the loop): the
+        # completed environment maps the final latents decode to, masked-out region included -- in this run's own arithmetic
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            img = m(m.Z[idx, :, :], D).float().numpy().copy()
+        return rec_at, terms, snaps, img
 
-    rec_at, terms, snaps = run(False)
-    _, terms_ac, snaps_ac = run(True)
+    rec_at, terms, snaps, img_final = run(False)
+    _, terms_ac, snaps_ac, img_final_ac = run(True)
     # the latent gradient AT the fp32 trajectory's latents (start, after 20 / 100 / 200 steps), in fp32 and under autocast: a
     # per-step comparison that does not go through 200 steps of Adam (trajectories diverge near stationarity, gradients do not)
     grads = {}
@@ -530,6 +536,7 @@ def g14():
     snaps.update({k + "_autocast_bf16": v for k, v in snaps_ac.items()})
     save("g14_c4_trajectory.npz", imgs=imgs.numpy(), mask=mask.numpy(), rec_at=np.array(rec_at), terms=np.array(terms),
          terms_autocast_bf16=np.array(terms_ac),
+         img_after_200=img_final.astype(np.float32), img_after_200_autocast_bf16=img_final_ac.astype(np.float16),
          W=np.int64(W), steps=np.int64(steps), lr=np.float64(1e-1), alpha=np.float64(1e-7), beta=np.float64(1e-4), **snaps)
 
 

@@ -201,7 +201,7 @@ def test_bench_default_line_carries_every_baseline_config_and_the_capi_exchange(
     the C ABI's reni_allreduce_grads (here a one-rank communicator: the same call path as N > 1)."""
     line = _run_bench({}, "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     curric = {"c2_curric_16x32", "c2_curric_32x64", "c2_curric_64x128"}   # configs/experiment.yaml:29-34, B = 100
-    assert set(line["also"]) == {"c4", "c4_dense", "c4_pixels", "c5", "film", "c2_b100", "c2_h256"} | curric, {k: v.get("error") for k, v in line["also"].items()}
+    assert set(line["also"]) == {"c4", "c4_dense", "c4_pixels", "c4_f32", "c5", "film", "c2_b100", "c2_h256"} | curric, {k: v.get("error") for k, v in line["also"].items()}
     assert all("error" not in v for v in line["also"].values()), {k: v.get("error") for k, v in line["also"].items()}
     assert line["also"]["c2_b100"]["images_per_gpu_per_step"] == 100
     # config 4 twice: with RENI_WEIGHT_SPARSE (what RENI.training_step passes with a mask; Mask-3: 148 of 256 tiles per image carry
@@ -218,6 +218,7 @@ def test_bench_default_line_carries_every_baseline_config_and_the_capi_exchange(
     for c, flop in (("c4", 348448), ("c4_dense", 348448), ("c4_pixels", 348448), ("c5", 177860), ("film", 424480), ("c2_h256", 2028320)):
         r = line["also"][c]
         assert r["value"] > 0 and r["ms_per_step"] > 0 and r["roofline"]["flop_per_sample"] == flop and r["roofline"]["kernel_avg_ms"] > 0
+        assert 0 < r["roofline"]["frac_step"] <= r["roofline"]["frac"] * 1.0001 and r["ms_per_step_mean"] >= r["ms_per_step"]
     for c in curric:
         r = line["also"][c]
         assert r["images_per_gpu_per_step"] == 100 and r["launches_per_step"] >= 2 and r["paths"]["env_overrides"] == []
@@ -226,6 +227,15 @@ def test_bench_default_line_carries_every_baseline_config_and_the_capi_exchange(
     # ONE definition of the headline: the contract's W + K window, first; the sustained-clock re-run is a side field
     assert line["steps"] == 3 and line["warmup"] == 1 and line["sustained"]["steps"] == 3 and "from_idle" not in line
     assert line["config"]["paths"]["dw1_kernel"] == "k_reni_l0_ring" and line["config"]["paths"]["env_overrides"] == []
+    # the three fractions side by side, the two kernels of the backward pass listed with their own times; 3: the
+    # parity-grade config 4; 5: effective vs visited samples
+    rf = line["roofline"]
+    assert rf["kernel"] == "k_reni_train_bf16<128,true,L0X>" and 0 < rf["frac_step"] < rf["frac"] and rf["kernel_min_ms"] <= rf["kernel_avg_ms"] <= rf["kernel_max_ms"]
+    assert [k["kernel"] for k in rf["kernels"]] == ["k_reni_train_bf16<128,true,L0X>", "k_reni_l0_ring"] and rf["kernels"][1]["avg_ms"] > 0
+    f32 = line["also"]["c4_f32"]
+    assert f32["dtype"] == "f32" and f32["roofline"]["peak"] == 157.3 and f32["roofline"]["flop_per_sample"] == 348448
+    assert line["also"]["c4"]["value_kind"] == "effective_samples_per_s" and line["also"]["c4_dense"]["value_kind"] == "samples_per_s"
+    assert abs(line["also"]["c4"]["visited_samples_per_s"] - line["also"]["c4"]["value"] * 148 / 256) <= 1e-6 * line["also"]["c4"]["value"]
     assert line["launches_per_step"] == int(line["launches_per_step"]) and 2 <= line["launches_per_step"] <= 16
     forced = _run_bench({"RENI_DW1_OLD": "1"}, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-also")
     assert forced["config"]["paths"]["dw1_kernel"] == "k_reni_dw1" and forced["config"]["paths"]["env_overrides"] == ["RENI_DW1_OLD"]

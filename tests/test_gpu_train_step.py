@@ -143,3 +143,53 @@ def test_latent_step_is_bit_equal_to_the_two_calls(dtype, H, L, W, sparse):
     for a, b, name in zip(res[False][1], res[True][1], ("Z", "m_lat", "v_lat")):
         assert torch.equal(a, b), (name, float((a - b).abs().max()))
     assert torch.isfinite(res[True][0]).all() and float(res[True][1][1].abs().max()) > 0
+
+
+@pytest.mark.parametrize("sparse", [True, "pixels"])
+def test_cached_weight_lists_follow_the_weight(sparse):
+    """reni_weight_lists_build / reni_latent_step_rows_cached: the lists are built once per mask and reused -- and
+    rebuilt when the weight tensor is modified in place (its version counter is part of the cache key) or replaced: every step bit-equal
+    to the entry point that rebuilds them in every call, with fewer launches."""
+    from reni_amd import ops
+    from reni_amd.engine import TrainEngine
+    from reni_amd.models import RENIAutoDecoder
+    dev = torch.device("cuda:0")
+    N, B, W = 6, 4, 128
+    D, S, T = _data(N, W, dev)
+    mask = torch.zeros(W // 2, W, 1)
+    mask[W // 8: W // 3, W // 4: (2 * W) // 3] = 1.0
+    Wm = (S * mask.reshape(1, -1, 1).to(dev)).clone()
+    idx = torch.arange(B, device=dev)
+    res, launches = {}, {}
+    for cached in (False, True):
+        torch.manual_seed(3)
+        m = RENIAutoDecoder(N, 9, "SO2", 128, 5, 3, True, "tanh", 30.0, 30.0, True)
+        with torch.no_grad():
+            m.Z.normal_(generator=torch.Generator().manual_seed(5))
+        m.set_compute_dtype("bf16").to(dev)
+        e = TrainEngine(m, lr=1e-1, loss_kind="test", alpha=1e-7, beta=1e-4, sparse_weight=sparse)
+        plan = m._plan()
+        w = Wm.clone()
+        terms = []
+        for k in range(6):
+            if k == 3:
+                w[:, : w.shape[1] // 2] = 0.0      # the mask changes IN PLACE: the cached lists must follow
+            if k == 5:
+                w = (S * 1.0).expand(1, -1, 3).clone()   # another tensor, no mask at all
+            ops.launch_count(reset=True)
+            t, _ = plan.latent_step(m.Z.data, idx, D, m._flat_params(), T[idx], w, e.m_lat, e.v_lat, k + 1, 1e-1, loss_kind="test",
+                                    alpha=1e-7, beta=1e-4, sparse_weight=sparse, cache_lists=cached)
+            launches.setdefault(cached, []).append(ops.launch_count(reset=True))
+            terms.append(t.clone())
+        torch.cuda.synchronize()
+        res[cached] = (torch.stack(terms), m.Z.data.clone())
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+    n_build = 3 if sparse == "pixels" else 2
+    # steps 1, 2, 4 reuse the lists (no list-building launch); steps 0, 3, 5 build them once (the same launches as the rebuilding call).
+    # While pixel 0 is masked (steps 0..4) the cosine term is a constant and the build says so: the statistics instance and
+    # k_stats_image -- two launches that would visit nothing -- are left out as well (RENI_WEIGHT_COS_CONSTANT).
+    for k in (1, 2, 4):
+        assert launches[True][k] == launches[False][k] - n_build - 2, (k, launches)
+    for k in (0, 3):
+        assert launches[True][k] == launches[False][k] - 2, (k, launches)
+    assert launches[True][5] == launches[False][5], launches

@@ -365,22 +365,31 @@ def test_c4_full_size_latent_step_bf16(dev):
     params, Z, D, W, T = random_problem(spec, B, 0, seed=44, grid_w=256)
     P = D.shape[1]
     assert P == 32768
-    keep = (torch.arange(256) < int(0.188 * 256)).float().view(1, 1, 256, 1).expand(1, 128, 256, 3).reshape(1, P, 3)
-    Wm = W * keep                                            # Mask-3's kept fraction
+    # the reference's REAL Mask-3 (data/Masks/Mask-3.png; its 256 x 512 source travels as data in g7_latent_opt.npz), resized as
+    # utils.get_mask does: rows 20-93 x columns 81-164 kept -- 148 of an image's 256 tiles carry weight, the block cuts through both
+    # tiles of every row it touches, pixel 0 is masked (the geometry the tile lists of RENI_WEIGHT_SPARSE actually see)
+    from reni_amd.utils import mask_from_array
+    keep = mask_from_array(256, load_golden("g7_latent_opt.npz")["mask_src"]).reshape(1, P, 3)
+    assert abs(float((keep.reshape(-1, 3) != 0).any(1).float().mean()) - 0.188) < 2e-3
+    Wm = W * keep
     plan = make_plan(spec, "bf16")
     fp = flat_params(spec, params).to(dev)
     Zd, Dd, Td, Wd = Z.to(dev), D.to(dev), T.to(dev), Wm.to(dev)
     a, b_ = 1e-7, 1e-4
 
-    def run(sel):
+    def run(sel, sparse=True):   # (RENI_WEIGHT_SPARSE: what RENI.training_step passes with a mask, lightning_module.py)
         lt, dZ, dp, _ = plan.forward_loss_backward(Zd[sel], Dd, fp, Td[sel], Wd, loss_kind="test", alpha=a, beta=b_,
-                                                   need_dw=False)
+                                                   need_dw=False, sparse_weight=sparse)
         assert dp is None
         return lt.cpu().double(), dZ.cpu()
 
     lt_all, dZ_all = run(slice(0, B))
     lt_again, dZ_again = run(slice(0, B))
     assert torch.equal(lt_all, lt_again) and torch.equal(dZ_all, dZ_again)          # deterministic reductions
+    lt_dense, dZ_dense = run(slice(0, B), sparse=False)                             # every tile + the statistics pass: the same bits
+    assert torch.equal(lt_all, lt_dense) and torch.equal(dZ_all, dZ_dense)
+    lt_px, dZ_px = run(slice(0, B), sparse="pixels")                                # RENI_WEIGHT_COMPACT: equal to rounding
+    assert O.rel_l2(dZ_px.numpy(), dZ_all.numpy()) <= 2e-6 and abs(float(lt_px[0] - lt_all[0])) <= 2e-6 * abs(float(lt_all[0]))
     # one image against the oracle at full P (reference-shaped: 32 768 x 1 370 encoding, autograd)
     k = 7
     ref = O.fwd_loss_bwd(spec, params, Z[k:k + 1], D, T[k:k + 1], Wm, "test", a, b_, need_dw=False)

@@ -252,6 +252,10 @@ def test_g14_g15_trajectories_start_from_the_oracle(golden):
             np.testing.assert_allclose(r["loss_terms"], g["terms"][rec[it]], rtol=2e-5, atol=1e-9)
         _adam(Z, r["dZ"], m, v, it + 1, float(g["lr"]))
     assert float((Z - torch.from_numpy(g["Z_after_20"])).abs().max()) <= 2e-3
+    # the loop's product: the oracle decodes the reference's final latents to the reference's completed maps (round 5: img_after_200)
+    img = O.reni_forward(spec, params, torch.from_numpy(g["Z_after_200"]), D)
+    assert float((img - torch.from_numpy(g["img_after_200"])).abs().max()) <= 5e-6
+    assert g["img_after_200_autocast_bf16"].shape == g["img_after_200"].shape
     g = golden("g15_c2_trajectory.npz")
     B, W = int(g["B"]), int(g["W"])
     D = O.get_directions(W).expand(B, -1, 3); S = O.get_sineweight(W).expand(B, -1, 3)
