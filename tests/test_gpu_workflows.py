@@ -480,6 +480,47 @@ def test_sparse_weight_leaves_out_only_exact_zeros(dev):
     assert torch.equal(g1[0], g0[0]) and torch.equal(g1[1], g0[1]) and torch.equal(g1[2], g0[2]), "training call with the flag"
 
 
+@pytest.mark.parametrize("poison", [0xFF, 0x7F, 0x00])
+def test_sparse_weight_with_a_poisoned_workspace(dev, poison):
+    """an intermittent failure of the test above inside the full suite (never alone, not reproduced since: 80 stress
+    iterations clean in round 5) pointed at a reader of workspace words the sparse path leaves unwritten -- records of unvisited tiles,
+    list tails, counts.  Here every byte of the plan's workspace is overwritten (0xFF: NaN floats, -1 indices; 0x7F: NaN floats, huge
+    positive indices; zeros) before EACH call: dense, tiles and pixels modes must give the results of the clean run, bit for bit
+    (tiles) / to rounding (pixels).  A reader of an unwritten word turns this into a deterministic failure (or a fault)."""
+    spec = O.DecoderSpec(36, "SO2", 128, 5, 3, True, "tanh")
+    B = 5
+    params, Z, D, W, T = random_problem(spec, B, 0, seed=91, grid_w=128)
+    P = D.shape[1]
+    m = torch.zeros(B, 64, 128, 1)
+    m[0, 10:46, 40:83] = 1.0
+    m[1] = 1.0
+    m[3, 33, 77] = 1.0
+    m[4, 10:46, 40:83] = 1.0
+    m[4, 0, 0] = 1.0
+    Wm = (W.view(1, 64, 128, 3) * m).reshape(B, P, 3)
+    plan = make_plan(spec, "bf16")
+    fp = flat_params(spec, params).to(dev)
+    Zd, Dd, Td, Wd = Z.to(dev), D.to(dev), T.to(dev), Wm.to(dev)
+
+    def run(sparse, dirty, n=B):
+        if dirty:
+            for ws in plan._ws.values():
+                ws.fill_(poison)
+        lt, dZ, _, _ = plan.forward_loss_backward(Zd[:n], Dd, fp, Td[:n], Wd[:n], loss_kind="test", alpha=1e-7, beta=1e-4, need_dw=False,
+                                                  sparse_weight=sparse)
+        return lt.cpu(), dZ.cpu()
+
+    clean = {mode: run(mode, False) for mode in (False, True, "pixels")}
+    assert plan._ws, "the plan keeps its workspace"
+    for n in (B, 3, 1):   # (odd list lengths, one image: other counts, other tails)
+        ref = {mode: run(mode, False, n) for mode in (False, True, "pixels")}
+        for mode in (False, True, "pixels"):
+            lt, dZ = run(mode, True, n)
+            assert torch.isfinite(dZ).all() and torch.isfinite(lt).all(), (mode, n)
+            assert torch.equal(lt, ref[mode][0]) and torch.equal(dZ, ref[mode][1]), (mode, n, float((dZ - ref[mode][1]).abs().max()))
+    assert torch.equal(clean[True][1], clean[False][1])
+
+
 @pytest.mark.parametrize("dtype,H,L", [("f32", 64, 3), ("f32", 128, 5), ("bf16", 256, 3), ("bf16", 64, 2)])
 def test_sparse_weight_on_the_generic_kernels(dev, dtype, H, L):
     """RENI_WEIGHT_SPARSE / RENI_WEIGHT_COMPACT off the persistent path: fp32 (the parity-grade arithmetic) and the widths without a
