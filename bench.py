@@ -210,6 +210,16 @@ def flop_train(nd, H, L):
     return 2 * (F + Bt)
 
 
+def flop_fwd(nd, H, L):
+    """forward only: 2 x ((ND+2) H + 2 ND + L H^2 + 3 H)  (ND=49, H=128, L=5: 177 860)"""
+    return 2 * ((nd + 2) * H + 2 * nd + L * H * H + 3 * H)
+
+
+def flop_frozen(nd, H, L):
+    """forward + the backward pass of a frozen decoder (dX GEMMs, the first layer's ND H + 2 ND): ND=36, H=128, L=5: 348 448"""
+    return flop_fwd(nd, H, L) + 2 * (L * H * H + 3 * H + nd * H + 2 * nd)
+
+
 _IMG_CACHE = {}
 
 
@@ -262,13 +272,13 @@ def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None,
     elif cfg == "c4":
         N_IMAGES, H_IMG, W_IMG, ND, B = 21, 128, 256, 36, batch or 21
         owned = list(range(N_IMAGES))  # every rank optimises its own 21 held-out maps (no shared state, no collective)
-        model = RENIAutoDecoder(N_IMAGES, ND, "SO2", 128, 5, 3, True, "tanh", 30.0, 30.0, True)
+        model = RENIAutoDecoder(N_IMAGES, ND, "SO2", hidden, 5, 3, True, "tanh", 30.0, 30.0, True)
         with torch.no_grad():
             model.Z.normal_()  # (fixed_decoder starts the latents at zero; any start costs the same)
     else:
         N_IMAGES, H_IMG, W_IMG, ND, B = 4, 512, 1024, 49, batch or 4
         owned = list(range(N_IMAGES))
-        model = RENIAutoDecoder(N_IMAGES, ND, eq, 128, 5, 3, True, "tanh", 30.0, 30.0, True)
+        model = RENIAutoDecoder(N_IMAGES, ND, eq, hidden, 5, 3, True, "tanh", 30.0, 30.0, True)
         with torch.no_grad():
             model.Z.normal_()
     model.set_compute_dtype(dtype)
@@ -397,15 +407,17 @@ def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, 
                     "layers x 128, mapping network 3 x 128, tanh; full training step (mapping network, fwd+loss+bwd, glue "
                     "backward, grad all-reduce, Adam over decoder + mapping network + latents)")
     elif cfg == "c4":
-        flop = FLOP_FROZEN
-        kernel = "k_reni_train_bf16<128,false>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD>"
-        workload = ("BASELINE config 4: test-time latent optimisation, 21 held-out maps, 128x256 equirect, ND=36, 5x128 SIREN, "
+        flop = flop_frozen(shape["ND"], H, 5)
+        assert H != 128 or flop == FLOP_FROZEN
+        kernel = ("k_reni_wide256<1>" if H == 256 else "k_reni_train_bf16<128,false>") if dtype == "bf16" else f"k_reni_main<f32,H={H},FWD_BWD>"
+        workload = (f"BASELINE config 4: test-time latent optimisation, 21 held-out maps, 128x256 equirect, ND=36, 5x{H} SIREN, "
                     "frozen decoder, the reference's Mask-3 (18.8 % kept), RENITestLoss(1e-7,1e-4) with the cosine term, per-image "
                     "latent Adam lr 0.1; full step (statistics pass where the cosine term is live + latent fwd/bwd + Adam)")
     else:
-        flop = FLOP_FWD_ND49
-        kernel = "k_reni_main<f32,H=128,FWD>" if dtype == "f32" else "k_reni_train_bf16<128,false,true>"
-        workload = f"BASELINE config 5: inference, 512x1024 directions, ND=49, 5x128 SIREN, {shape['eq']}, 4 images per step"
+        flop = flop_fwd(shape["ND"], H, 5)
+        assert H != 128 or flop == FLOP_FWD_ND49
+        kernel = f"k_reni_main<f32,H={H},FWD>" if dtype == "f32" else ("k_reni_wide256<0>" if H == 256 else "k_reni_train_bf16<128,false,true>")
+        workload = f"BASELINE config 5: inference, 512x1024 directions, ND=49, 5x{H} SIREN, {shape['eq']}, 4 images per step"
     # achieved = the algorithmic FLOPs of the timed steps / the dominant kernel's total run time in them (HIP events on its stream):
     # per launch this is flop x samples per launch / average launch duration, also when a step is several launches (H = 256: chunks)
     # (c4 with RENI_WEIGHT_SPARSE: only the tiles the kernel visits are counted -- `value` counts every direction of the images, as the
@@ -487,6 +499,12 @@ def sub_record(name, args, rank, world, dev):
         m = run_config("c4", args, rank, world, dev, force_dtype="f32", **kw)   # only the loss curve, must track the reference
     elif name == "c2_h256":   # the width of the reference's shipped configs (configs/default.py:13)
         m = run_config("c2", args, rank, world, dev, hidden=256, **kw)
+    elif name == "c4_h256":   # config 4's step at that width (k_reni_wide256: round 5), RENI_WEIGHT_SPARSE as RENI.training_step passes it
+        m = run_config("c4", args, rank, world, dev, hidden=256, **kw)
+    elif name == "c4_h256_dense":
+        m = run_config("c4", args, rank, world, dev, hidden=256, dense=True, **kw)
+    elif name == "fwd_h256":  # config 5's shape (4 x 524 288 directions, ND = 49) forward at H = 256 in bf16
+        m = run_config("c5", args, rank, world, dev, hidden=256, force_dtype="bf16", **kw)
     else:
         m = run_config(name, args, rank, world, dev, **kw)
     # Two windows of W + K steps, the faster one reported and both listed: a sub-millisecond step is several host calls, and on a
@@ -494,9 +512,9 @@ def sub_record(name, args, rank, world, dev):
     # unchanged; profiles/tools/gpu_c4_twice.py).  Sub-records only -- the headline is its one contract window.
     wins = [m(), m()]
     r = min(wins, key=lambda x: x["ms_per_step"])
-    out = {"metric": METRIC_FWD if name == "c5" else METRIC_TRAIN.replace("128x256", "%dx%d" % tuple(int(x) for x in name[10:].split("x")))
+    out = {"metric": METRIC_FWD if name in ("c5", "fwd_h256") else METRIC_TRAIN.replace("128x256", "%dx%d" % tuple(int(x) for x in name[10:].split("x")))
            if name.startswith("c2_curric_") else METRIC_TRAIN,
-           "value": r["value"] / (world if name in ("c4", "c4_dense", "c4_pixels", "c4_f32", "c5") else 1), "unit": "samples/s",
+           "value": r["value"] / (world if name in ("c4", "c4_dense", "c4_pixels", "c4_f32", "c5", "c4_h256", "c4_h256_dense", "fwd_h256") else 1), "unit": "samples/s",
            "ms_per_step": r["ms_per_step"], "ms_per_step_windows": [w_["ms_per_step"] for w_ in wins],
            "ms_per_step_mean": sum(w_["ms_per_step"] for w_ in wins) / len(wins),   # (not only the faster window)
            "steps": r["steps"], "launches_per_step": r["launches_per_step"],
@@ -556,7 +574,7 @@ def main():
         # configurations whose ranks are independent (c4, c5: rank 0's own replica).
         also = {}
         user_dtype = args.dtype
-        names = (("c4", "c4_dense", "c4_pixels", "c4_f32", "c5", "film", "c2_b100") + tuple(f"c2_curric_{h}x{w}" for h, w in CURRIC) + ("c2_h256",)) if world == 1 else ("c4", "c5")
+        names = (("c4", "c4_dense", "c4_pixels", "c4_f32", "c5", "film", "c2_b100") + tuple(f"c2_curric_{h}x{w}" for h, w in CURRIC) + ("c2_h256", "c4_h256", "c4_h256_dense", "fwd_h256")) if world == 1 else ("c4", "c5")
         for c in names:
             args.dtype = None
             try:

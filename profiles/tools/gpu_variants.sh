@@ -11,7 +11,7 @@ done
 ROOT=$(cd "$(dirname "$0")/../.."; pwd)
 cd $ROOT/reni_amd/csrc; mkdir -p _build
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-spill-vgpr-to-agpr=0 -I../../include"
-OBJS="core main_f32 main_bf16 film_f32 film_bf16 train_film shade image"
+OBJS="core main_f32 main_bf16 film_f32 film_bf16 train_film wide shade image"
 i=0; pids=()
 for v in "$@"; do
   if [ "$v" != "@base" ]; then hipcc $FL $v -c reni_tu_$TU.hip -o _build/${TU}_v$i.o 2>_build/${TU}_v$i.err & pids+=($!); fi

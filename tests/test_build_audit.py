@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 CSRC = os.path.join(ROOT, "reni_amd", "csrc")
-TUS = ("core", "main_f32", "main_bf16", "film_f32", "film_bf16", "train_film")
+TUS = ("core", "main_f32", "main_bf16", "film_f32", "film_bf16", "train_film", "wide")
 _ISA = {}
 
 

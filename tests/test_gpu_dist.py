@@ -201,7 +201,7 @@ def test_bench_default_line_carries_every_baseline_config_and_the_capi_exchange(
     the C ABI's reni_allreduce_grads (here a one-rank communicator: the same call path as N > 1)."""
     line = _run_bench({}, "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     curric = {"c2_curric_16x32", "c2_curric_32x64", "c2_curric_64x128"}   # configs/experiment.yaml:29-34, B = 100
-    assert set(line["also"]) == {"c4", "c4_dense", "c4_pixels", "c4_f32", "c5", "film", "c2_b100", "c2_h256"} | curric, {k: v.get("error") for k, v in line["also"].items()}
+    assert set(line["also"]) == {"c4", "c4_dense", "c4_pixels", "c4_f32", "c5", "film", "c2_b100", "c2_h256", "c4_h256", "c4_h256_dense", "fwd_h256"} | curric, {k: v.get("error") for k, v in line["also"].items()}
     assert all("error" not in v for v in line["also"].values()), {k: v.get("error") for k, v in line["also"].items()}
     assert line["also"]["c2_b100"]["images_per_gpu_per_step"] == 100
     # config 4 twice: with RENI_WEIGHT_SPARSE (what RENI.training_step passes with a mask; Mask-3: 148 of 256 tiles per image carry
