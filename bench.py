@@ -396,8 +396,9 @@ def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, 
         flop = flop_train(shape["ND"], H, 5)
         assert H != 128 or flop == FLOP_TRAIN
         l0x = isinstance(paths, dict) and paths.get("dw1_kernel") == "k_reni_l0_ring"   # (round 5: the L0X instance + k_reni_l0_ring)
+        wide = dtype == "bf16" and H == 256 and isinstance(paths, dict) and paths.get("persistent_kernels")  # (round 5: k_reni_wide256<2> feeds k_dw_frag)
         kernel = (("k_reni_train_bf16<128,true,L0X>" if l0x else "k_reni_train_bf16<128,true>") if (dtype == "bf16" and H == 128)
-                  else f"k_reni_main<{dtype},H={H},FWD_BWD>")
+                  else "k_reni_wide256<2>" if wide else f"k_reni_main<{dtype},H={H},FWD_BWD>")
         workload = (f"BASELINE config 2: 615-image set, {shape['res'][0]}x{shape['res'][1]} equirect, ND=36, 5x{H} SIREN, SO2, tanh, "
                     "AutoDecoder, RENITrainLoss; full training step (fwd+loss+bwd, grad all-reduce, Adam)")
     elif cfg == "film":

@@ -119,6 +119,39 @@ def test_release_library_has_no_result_changing_debug_knobs():
     assert b"RENI_NO_PERSIST" in blob and b"RENI_NO_SIDE_STREAM" in blob
 
 
+def _vm_ops_before(lines, site, need):
+    """The `need` newest vector-memory operations in the text in front of line `site` (newest first).  hipcc places out-of-line blocks
+    (e.g. a lane-conditional LDS-DMA issued early in the step, which jumps back to where it came from) between a kernel's last stores
+    and the wait behind them: a block that cannot be fallen into, and that ends in an unconditional branch BACK to a label in front of
+    every operation counted here, cannot run between those operations and the wait -- its operations are left out."""
+    code = [l.split(";")[0].strip() for l in lines]
+    label_at = {t[:-1]: i for i, t in enumerate(code) if re.match(r"\.LBB\d+_\d+:$", t)}
+    uncond = ("s_branch", "s_endpgm", "s_setpc")
+    skip_to, back_target = {}, {}   # last line of an out-of-line block -> its first line / the line its closing branch targets
+    for lab, i in label_at.items():
+        prev = next((code[q] for q in range(i - 1, 0, -1) if code[q]), "")
+        if not prev.startswith(uncond):
+            continue
+        j = next((q for q in range(i, len(code)) if code[q].startswith(uncond)), None)
+        if j is None or not code[j].startswith("s_branch"):
+            continue
+        tgt = label_at.get(code[j].split()[1])
+        if tgt is not None and tgt < i and j < site:
+            skip_to[j], back_target[j] = i, tgt
+    vm, k, latest_target = [], site - 1, None
+    while k > 0 and len(vm) < need:
+        if k in skip_to:
+            latest_target = back_target[k] if latest_target is None else max(latest_target, back_target[k])
+            k = skip_to[k] - 1
+            continue
+        t = code[k]
+        if t.startswith(("global_", "scratch_", "buffer_", "flat_")):
+            vm.append(t.split()[0])
+        k -= 1
+    assert latest_target is None or latest_target < k + 1, "an out-of-line block returns to a point behind the counted operations"
+    return vm
+
+
 def test_counted_wait_in_front_of_the_dA_phase_covers_the_weight_image():
     """k_reni_train_bf16<128,true> waits `vmcnt(8)` (not 0) for the next tile's first weight image in front of the layer-0
     dA phase: legal only if the eight newest vector-memory operations at that point are the g_1 stream's stores and every
@@ -133,12 +166,6 @@ def test_counted_wait_in_front_of_the_dA_phase_covers_the_weight_image():
         sites = [i for i, l in enumerate(lines) if l.startswith("s_waitcnt vmcnt(8)") and "ASMSTART" in lines[i - 1]]
         assert sites, "the counted wait is gone: update this audit with the code"
         for i in sites:
-            vm = []
-            for k in range(i - 1, 0, -1):
-                t = lines[k].split(";")[0].strip()
-                if t.startswith(("global_", "scratch_", "buffer_", "flat_")):
-                    vm.append(t.split()[0])
-                if len(vm) == 17:
-                    break
-            assert vm[:8] == ["global_store_dwordx4"] * 8, vm[:10]
-            assert vm[8:17] == ["global_load_lds_dwordx4"] * 9, vm[8:17]
+            vm = _vm_ops_before(lines, i - 1, 17)
+            assert vm[:8] == ["global_store_dwordx4"] * 8, (inst[-24:], vm[:10])
+            assert vm[8:17] == ["global_load_lds_dwordx4"] * 9, (inst[-24:], vm[8:17])
