@@ -66,6 +66,9 @@ def parse():
                     help="images per GPU per step (c2: 64, <= 615/8 so that 8 ranks can own them; c4: 21; c5: 4)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32"], help="c2 / c4: bf16, c5: f32")
     ap.add_argument("--res", default=None, help="c2 only: HxW of the equirect grid (e.g. 16x32: one stage of the curriculum on its own)")
+    ap.add_argument("--hidden", type=int, default=128, choices=[128, 256],
+                    help="c4 / c5: the SIREN's width (256: the reference's shipped width -- the sub-records c4_h256 / fwd_h256 on their own, "
+                         "for the counter passes of profiles/tools/gpu_profile_round.sh; c5 then runs in bf16)")
     ap.add_argument("--dense", action="store_true", help="c4: RENI_WEIGHT_SPARSE off (every tile, and the statistics pass)")
     ap.add_argument("--pixels", action="store_true", help="c4: RENI_WEIGHT_COMPACT (pixels with weight packed into each image's first tiles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -566,7 +569,9 @@ def main():
         head = run_config("c2", args, rank, world, dev, batch=args.batch, hidden=256, defer=True)
     else:
         res = tuple(int(x) for x in args.res.split("x")) if (args.res and cfg == "c2") else None
-        head = run_config(cfg, args, rank, world, dev, batch=args.batch, res=res, defer=True, dense=args.dense, pixels=args.pixels)  # set-up only
+        wide = args.hidden == 256 and cfg in ("c4", "c5")
+        head = run_config(cfg, args, rank, world, dev, batch=args.batch, res=res, defer=True, dense=args.dense, pixels=args.pixels,
+                          hidden=256 if wide else 128, force_dtype="bf16" if (wide and cfg == "c5") else None)  # set-up only
     # THE headline: W warm-up + K timed steps, first, identically with and without the sub-records
     rec = head()
     if cfg == "c2" and not args.no_also:
