@@ -326,6 +326,8 @@ def test_pmc_traffic_record_belongs_to_the_committed_kernel_sources():
     import bench
     rec = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
     sha = bench.kernel_src_sha()
-    for kernel in ("k_reni_train_bf16<128,true>", "k_reni_train_bf16<128,false>", "k_reni_main<f32,H=128,FWD>"):
+    # (round 5: the L0X instance and k_reni_l0_ring are what config 2 runs; the H = 256 chain's three forms have entries of their own)
+    for kernel in ("k_reni_train_bf16<128,true,L0X>", "k_reni_l0_ring", "k_reni_train_bf16<128,false>", "k_reni_main<f32,H=128,FWD>",
+                   "k_reni_wide256<0>", "k_reni_wide256<1>", "k_reni_wide256<2>"):
         assert rec[kernel]["src_sha256"] == sha, f"{kernel}: PMC record is of another source state"
         assert bench.pmc_record(kernel).get("hbm_bytes_per_launch"), kernel
