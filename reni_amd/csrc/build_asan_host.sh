@@ -8,7 +8,7 @@ mkdir -p _build/asan
 FLAGS="--offload-arch=gfx950 --cuda-host-only -O1 -g -std=c++17 -fPIC -fsanitize=address -fno-omit-frame-pointer -I../../include"
 pids=()
 rm -f _build/asan/*.o _build/asan/*.stub
-for tu in core main_f32 main_bf16 film_f32 film_bf16 train_film shade image; do
+for tu in core main_f32 main_bf16 film_f32 film_bf16 train_film wide shade image; do
   hipcc $FLAGS -c reni_tu_$tu.hip -o _build/asan/$tu.o &
   pids+=($!)
 done
@@ -20,4 +20,4 @@ for p in "${pids[@]}"; do wait "$p"; done
 /opt/rocm/lib/llvm/bin/clang -c _build/asan/fatbin_stubs.c -o _build/asan/fatbin_stubs.o.stub
 /opt/rocm/lib/llvm/bin/clang -O1 -g -fsanitize=address -fno-omit-frame-pointer -I../../include -c ../../tests/capi/capi_args.c -o _build/asan/capi_args.o
 hipcc -fsanitize=address _build/asan/capi_args.o _build/asan/fatbin_stubs.o.stub _build/asan/core.o _build/asan/main_f32.o _build/asan/main_bf16.o _build/asan/film_f32.o \
-  _build/asan/film_bf16.o _build/asan/train_film.o _build/asan/shade.o _build/asan/image.o -o _build/asan/capi_args
+  _build/asan/film_bf16.o _build/asan/train_film.o _build/asan/wide.o _build/asan/shade.o _build/asan/image.o -o _build/asan/capi_args

@@ -82,3 +82,32 @@ def test_wide_training_form_in_image_chunks(dev):
     assert abs(float(a[0][0]) - float(b[0][0])) <= 1e-5 * abs(float(a[0][0]))
     assert torch.equal(a[1], b[1])  # an image's dZ does not depend on its neighbours
     assert O.rel_l2(b[2].cpu().numpy(), a[2].cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("B,P", [(1, 128), (3, 384), (1, 100)])
+def test_wide_kernel_with_an_odd_number_of_tiles(dev, B, P):
+    """k_reni_wide256 works on two tiles per workgroup: with an odd tile count (one tile; nine; one ragged tile) the last pair's second
+    group is idle -- forward, frozen-decoder and training forms against the oracle, and the image's result independent of the pairing
+    (a batch of 2 B images gives every image the bits it has in a batch of B: its tiles then sit in other groups / pairs)."""
+    spec = O.DecoderSpec(9, "SO2", 256, 5, 3, True, "tanh")
+    params, Z, D, W, T = random_problem(spec, 2 * B, P, seed=40 + P, per_image_dirs=True)
+    plan = make_plan(spec, "bf16")
+    fp = flat_params(spec, params).to(dev)
+    Zd, Dd, Td, Wd = Z.to(dev), D.to(dev), T.to(dev), W.to(dev)
+    pn = {k: v.numpy() for k, v in params.items()}
+    ref = O.factored_fwd_bwd(spec, pn, Z[:B].numpy(), D[:B].numpy(), T[:B].numpy(), W.numpy())
+    out = plan.forward(Zd[:B], Dd[:B], fp).clone()                                             # MODE 0
+    assert (out.cpu().numpy() - ref["out"]).__abs__().max() <= 2e-2
+    assert torch.equal(plan.forward(Zd, Dd, fp)[:B], out)
+    for need_dw in (False, True):                                                              # MODE 1, MODE 2
+        lt, dZ, dp, _ = plan.forward_loss_backward(Zd[:B], Dd[:B], fp, Td[:B], Wd, need_dw=need_dw)
+        lt, dZ = lt.clone(), dZ.clone()
+        dp = dp.clone() if need_dw else None
+        assert abs(float(lt[0]) - ref["loss_terms"][0]) <= 3e-3 * abs(ref["loss_terms"][0])
+        assert O.rel_l2(dZ.cpu().numpy(), ref["dZ"]) <= 3e-2
+        if need_dw:
+            gp = unflatten(spec, dp.cpu())
+            for k in gp:
+                assert O.rel_l2(gp[k].numpy(), ref["grads"][k]) <= 3e-2, k
+        _, dZ2, _, _ = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd, need_dw=need_dw)
+        assert torch.equal(dZ2[:B], dZ)   # an image's gradient does not depend on which group / pair its tiles land in
