@@ -85,3 +85,36 @@ def test_l0x_rows_by_lds_dma_in_both_layouts(dev):
     r_u = plan.forward_loss_backward(Zd, Dd, fp, Tu, Wi)[:3]
     assert abs(float(r_u[0][0]) - float(r_i[0][0])) <= 1e-6 * abs(float(r_i[0][0]))
     assert O.rel_l2(r_u[1].cpu().numpy(), r_i[1].cpu().numpy()) <= 2e-3 and O.rel_l2(r_u[2].cpu().numpy(), r_i[2].cpu().numpy()) <= 2e-3
+
+
+@pytest.mark.parametrize("H,eq", [(128, "SO2"), (256, "SO2")])
+@pytest.mark.parametrize("poison", [0xFF, 0x7F])
+def test_training_paths_with_a_poisoned_workspace(dev, H, eq, poison):
+    """Every byte of the plan's workspace overwritten (0xFF: NaN floats, -1 integers; 0x7F: NaN floats, huge integers) before the
+    call: the training step's kernels -- the L0X instance, k_reni_l0_ring with its image-run records and g_1 stream, the fused tails
+    (H = 128); k_reni_wide256's training and frozen forms with their per-tile stash, fragment and g_y streams, k_dw_frag,
+    k_wide_head_dw (H = 256) -- must give the clean run's bits.  A reader of a word the call did not write fails here deterministically.
+    Shapes: ranges crossing images with a ragged tail of tiles (B = 5 images of 32 tiles over 256 workgroups -> one tile per workgroup,
+    fewer tiles than workgroups), and many tiles per workgroup."""
+    spec = O.DecoderSpec(36, eq, H, 5, 3, True, "tanh")
+    for B, gw in ((5, 64), (3, 256) if H == 128 else (2, 128)):
+        params, Z, D, W, T = random_problem(spec, B, 0, seed=3 + B, grid_w=gw)
+        plan = make_plan(spec, "bf16")
+        fp = flat_params(spec, params).to(dev)
+        Zd, Dd, Td, Wd = Z.to(dev), D.to(dev), T.to(dev), W.to(dev)
+
+        def run(dirty, need_dw):
+            if dirty:
+                for ws in plan._ws.values():
+                    ws.fill_(poison)
+            lt, dZ, dp, _ = plan.forward_loss_backward(Zd, Dd, fp, Td, Wd, need_dw=need_dw)
+            return lt.cpu(), dZ.cpu(), (dp.cpu() if need_dw else None)
+
+        for need_dw in (True, False):
+            ref = run(False, need_dw)
+            assert plan._ws, "the plan keeps its workspace"
+            got = run(True, need_dw)
+            assert torch.isfinite(got[0]).all() and torch.isfinite(got[1]).all()
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (B, need_dw)
+            if need_dw:
+                assert torch.isfinite(got[2]).all() and torch.equal(got[2], ref[2]), (B, float((got[2] - ref[2]).abs().max()))
