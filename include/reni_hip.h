@@ -119,6 +119,8 @@ int32_t reni_in_features(const reni_plan* plan);
  *   bf16, H = 256                  (2 L + 1) x 64 KB per tile: every tile's phase stash + the g_l fragment stream (k_dw_frag)
  *   fp32, H = 256, concat          (2 L + 1) x 128 KB per tile: the same in fp32 (k_dw_frag32)
  * e.g. 64 images x 32768 directions (16 384 tiles): 0.7 GB at 5 x 128, 11 GB at 5 x 256 bf16, 23 GB at 5 x 256 fp32.
+ * (H = 256 training: a call whose stream would exceed 16 GB -- RENI_FRAG_WS_CAP_MB overrides -- runs in equal chunks of whole images,
+ * one after the other, and the workspace is sized for one chunk: the fp32 example above is two passes of 32 images, 11.5 GB each.)
  * The H <= 128 stash ring and the per-workgroup gradient partials do not grow with B x P. */
 size_t reni_workspace_bytes(const reni_plan* plan, int64_t B, int64_t P, uint32_t flags);
 
