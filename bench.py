@@ -381,6 +381,7 @@ def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, 
     kern_ms, kern_n = ops.profile_read(reset=False, kind=kind)
     kern_min, kern_max = ops.profile_minmax(kind)
     dw1_ms, dw1_n = ops.profile_read(reset=False, kind=ops.PROF_DW1)
+    dw1_min, dw1_max = ops.profile_minmax(ops.PROF_DW1) if dw1_n else (None, None)
     stats_ms, stats_n = ops.profile_read(reset=True, kind=ops.PROF_STATS)
     ops.profile_enable(False)
     comm_us = eng.time_comm(False) if eng is not None else None
@@ -449,7 +450,7 @@ def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, 
         a2 = dw1_ms / dw1_n
         roof["kernels"] = [
             {"kernel": kernel, "avg_ms": kavg_ms, "frac_issued": roof["frac_issued"], "traffic": pmc.get("hbm_bytes_per_launch")},
-            {"kernel": k2, "avg_ms": a2, "launches": dw1_n, "traffic": p2.get("hbm_bytes_per_launch"),
+            {"kernel": k2, "avg_ms": a2, "min_ms": dw1_min, "max_ms": dw1_max, "launches": dw1_n, "traffic": p2.get("hbm_bytes_per_launch"),
              "frac_issued": (p2["mfma_per_launch"] * mfma_flop / (a2 * 1e-3) / 1e12 / PEAK_TFLOPS[dtype]) if p2.get("mfma_per_launch") else None,
              "hbm_frac": (p2["hbm_bytes_per_launch"] / (a2 * 1e-3) / 8e12) if p2.get("hbm_bytes_per_launch") else None}]
     if pmc.get("valu_per_mfma"):
