@@ -76,9 +76,12 @@ def parse():
     ap.add_argument("--no-also", action="store_true", help="skip the c4 / c5 / film sub-records of the default (c2) line")
     ap.add_argument("--no-fused-step", action="store_true",
                     help="the training step as two library calls (fwd+loss+bwd, then Adam) instead of reni_train_step_rows")
-    ap.add_argument("--comm", default="torch", choices=["torch", "capi"],
-                    help="the step's exchange (decoder-gradient all-reduce): torch.distributed's nccl backend, or the C ABI's "
-                         "reni_allreduce_grads on an RCCL communicator the library owns")
+    ap.add_argument("--comm", default=None, choices=["torch", "capi"],
+                    help="the step's exchange (decoder-gradient all-reduce).  capi: an RCCL communicator the library owns -- the step is "
+                         "then reni_train_step_rows_dp, the SAME fused call N = 1 runs with the all-reduce inside it (the default at "
+                         "N > 1 on the nccl backend; if the communicator cannot be created the line says so in `comm_fallback`).  "
+                         "torch: torch.distributed's collective between forward_loss_backward_rows and adam_step2 (three calls; the "
+                         "opt-out, and what a gloo job gets).  N = 1 default: no communicator at all")
     return ap.parse_args()
 
 
@@ -166,9 +169,8 @@ def cpu_baseline(n_steps):
     return {"value": max(res["port_b1"], res["port_b4"]), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "port_b1": res["port_b1"], "port_b4": res["port_b4"],
             "factored": max(res["factored_b1"], res["factored_b4"]), "factored_b1": res["factored_b1"], "factored_b4": res["factored_b4"],
-            "sample": f"config-2 shape (128x256 directions, ND=36, 5x128, fp32), B=1 and B=4 images per step, 3 warm-up + "
-                      f"{n_steps} timed fwd+loss+bwd steps each, median; port = reference-shaped (materialised 1370-column "
-                      f"encoding + autograd), factored = per-image affine first layer + autograd"}
+            "sample": f"config-2 shape (128x256, ND=36, 5x128, fp32), B=1 and B=4 images/step, 3 warm-up + {n_steps} timed fwd+loss+bwd "
+                      f"steps each, median; port = reference-shaped (1370-column encoding + autograd), factored = per-image affine first layer"}
 
 
 def kernel_src_sha():
@@ -224,6 +226,41 @@ def flop_frozen(nd, H, L):
 
 
 _IMG_CACHE = {}
+_COMM = {}   # the library-owned RCCL communicator of this process (one per process: every configuration of a run shares it)
+
+
+def _want_capi(args, world):
+    """--comm capi, or no --comm at N > 1: the fused data-parallel step on the library's own communicator (whatever backend the torch
+    group runs on -- the group only carries the 128-byte unique id and the barriers)."""
+    if args.comm is not None:
+        return args.comm == "capi"
+    return world > 1
+
+
+def _rccl_comm(args, rank, world, dev):
+    """The communicator, created once.  A failure here is collective (ncclCommInitRank fails or hangs on every rank alike), and every
+    rank must take the same branch: the ranks agree through the torch group, and on a fallback the line carries `comm_fallback`."""
+    import torch
+    from reni_amd import dist as rdist
+    if "comm" not in _COMM:
+        comm, err = None, None
+        try:
+            comm = rdist.RcclComm(rank, world)
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"[:200]
+        if world > 1:
+            ok = torch.tensor([0 if comm is None else 1], device=dev)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            if int(ok) == 0 and comm is not None:
+                comm.close()
+                comm, err = None, "another rank could not create the communicator"
+        if comm is None and args.comm == "capi":
+            raise RuntimeError(f"--comm capi: {err}")
+        _COMM["comm"], _COMM["error"] = comm, err
+        if comm is None:
+            print(f"bench.py: the library's RCCL communicator could not be created ({err}); falling back to torch.distributed's "
+                  "all-reduce between forward_loss_backward_rows and adam_step2", file=sys.stderr, flush=True)
+    return _COMM["comm"]
 
 
 def _resident_images(n_images, h, w, owned, dev):
@@ -301,8 +338,8 @@ def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None,
     if cfg in ("c2", "c4", "film"):
         imgs = _resident_images(N_IMAGES, H_IMG, W_IMG, owned, dev)  # resident in HBM before the timed region; ~0.39 MB per image
         comm = None
-        if args.comm == "capi" and cfg in ("c2", "film"):  # the exchange step through the C ABI's reni_allreduce_grads
-            comm = rdist.RcclComm(rank, world)
+        if _want_capi(args, world) and cfg in ("c2", "film"):  # the exchange step inside the library (reni_train_step_rows_dp / reni_allreduce_grads)
+            comm = _rccl_comm(args, rank, world, dev)
         if cfg in ("c2", "film"):
             eng = TrainEngine(model, lr=1e-5, comm=comm, fused_step=not args.no_fused_step)
             weight = sineweight
@@ -382,9 +419,11 @@ def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, 
     kern_min, kern_max = ops.profile_minmax(kind)
     dw1_ms, dw1_n = ops.profile_read(reset=False, kind=ops.PROF_DW1)
     dw1_min, dw1_max = ops.profile_minmax(ops.PROF_DW1) if dw1_n else (None, None)
-    stats_ms, stats_n = ops.profile_read(reset=True, kind=ops.PROF_STATS)
+    dws_ms, dws_n = ops.profile_read(reset=False, kind=ops.PROF_DWS)
+    stats_ms, stats_n = ops.profile_read(reset=False, kind=ops.PROF_STATS)
+    comm_us = eng.time_comm(False) if eng is not None else None   # (the fused data-parallel step: the library's PROF_COMM pairs)
+    ops.profile_read(reset=True, kind=ops.PROF_ALL)
     ops.profile_enable(False)
-    comm_us = eng.time_comm(False) if eng is not None else None
     check = float(last[0]) if cfg != "c5" else float(last.abs().max())
     assert check == check and abs(check) < 1e6, f"non-finite result {check}"
 
@@ -428,37 +467,46 @@ def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, 
     # (c4 with RENI_WEIGHT_SPARSE: only the tiles the kernel visits are counted -- `value` counts every direction of the images, as the
     # reference evaluates them all for the same result)
     visited = shape["sparsity"]["tiles_visited"] if shape.get("sparsity") else 1.0
-    achieved = visited * B * P * steps * flop / (max(kern_ms, 1e-9) * 1e-3) / 1e12
-    pmc = pmc_record(kernel)
-    # Three fractions of the same peak, so that moving FLOPs between kernels cannot improve the number by relabelling:
-    #   frac        SURVEY 8(d)'s yardstick: ALL algorithmic FLOPs of the step over the DOMINANT kernel's run time
-    #   frac_step   the same FLOPs over the whole step's wall time (every kernel, every gap)
-    #   frac_issued per kernel: the MFMA FLOPs it actually issues (SQ_INSTS_MFMA of the PMC passes x FLOP per instruction) over its own
-    #               HIP-event time -- `kernels` lists the training kernel and the kernel that finishes the backward pass behind it
     step_flops = visited * B * P * steps * flop
+    # `frac`: the algorithmic FLOPs of the timed steps over the SUMMED run time of the kernels that perform them -- the chain
+    # kernel plus whatever finishes the backward pass behind it (k_reni_l0_ring / k_reni_dw1*: PROF_DW1; k_dw_frag / k_dw_stream /
+    # k_wide_head_dw: PROF_DWS), each timed with HIP events on its own stream.  Moving work from one kernel into another cannot raise it.
+    #   frac_step   the same FLOPs over the whole step's wall time (every kernel, every gap)
+    #   frac_issued per kernel: the MFMA FLOPs it issues (SQ_INSTS_MFMA of the PMC passes x FLOP per instruction) over its own time
+    work_ms = kern_ms + dw1_ms + dws_ms
+    achieved = step_flops / (max(work_ms, 1e-9) * 1e-3) / 1e12
+    pmc = pmc_record(kernel)
+    peak = PEAK_TFLOPS[dtype]
     mfma_flop = 32768.0 if dtype == "bf16" else 4096.0   # v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32
-    roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-            "frac": achieved / PEAK_TFLOPS[dtype], "frac_step": step_flops / dt / 1e12 / PEAK_TFLOPS[dtype],
-            "frac_issued": (pmc["mfma_per_launch"] * mfma_flop / (kavg_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype])
-            if pmc.get("mfma_per_launch") and kavg_ms > 0 else None,
+
+    def issued(rec, avg_ms):
+        return (rec["mfma_per_launch"] * mfma_flop / (avg_ms * 1e-3) / 1e12 / peak) if rec.get("mfma_per_launch") and avg_ms > 0 else None
+
+    roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "frac": achieved / peak, "frac_step": step_flops / dt / 1e12 / peak, "frac_issued": issued(pmc, kavg_ms),
             "traffic": pmc.get("hbm_bytes_per_launch"), "kernel": kernel,
             "kernel_avg_ms": kavg_ms, "kernel_min_ms": kern_min, "kernel_max_ms": kern_max, "kernel_launches": kern_n,
-            "flop_per_sample": flop}
+            "work_kernels_ms_per_step": work_ms / steps, "flop_per_sample": flop}
+    kernels = [{"kernel": kernel, "avg_ms": kavg_ms, "frac_issued": roof["frac_issued"], "traffic": pmc.get("hbm_bytes_per_launch")}]
     if dw1_n:
+        # (named from the kernel the call LAUNCHED -- reni_path_info answers for the plan, the L0X form also needs WeightedMSE,
+        #  no output image and 16-byte aligned target / weight rows; bench's step meets them, and the PROF_DW1 pairs exist only if it ran)
         k2 = paths.get("dw1_kernel", "k_reni_dw1") if isinstance(paths, dict) else "k_reni_dw1"
         p2 = pmc_record(k2)
         a2 = dw1_ms / dw1_n
-        roof["kernels"] = [
-            {"kernel": kernel, "avg_ms": kavg_ms, "frac_issued": roof["frac_issued"], "traffic": pmc.get("hbm_bytes_per_launch")},
-            {"kernel": k2, "avg_ms": a2, "min_ms": dw1_min, "max_ms": dw1_max, "launches": dw1_n, "traffic": p2.get("hbm_bytes_per_launch"),
-             "frac_issued": (p2["mfma_per_launch"] * mfma_flop / (a2 * 1e-3) / 1e12 / PEAK_TFLOPS[dtype]) if p2.get("mfma_per_launch") else None,
-             "hbm_frac": (p2["hbm_bytes_per_launch"] / (a2 * 1e-3) / 8e12) if p2.get("hbm_bytes_per_launch") else None}]
+        kernels.append({"kernel": k2, "avg_ms": a2, "min_ms": dw1_min, "max_ms": dw1_max, "launches": dw1_n,
+                        "traffic": p2.get("hbm_bytes_per_launch"), "frac_issued": issued(p2, a2),
+                        "hbm_frac": (p2["hbm_bytes_per_launch"] / (a2 * 1e-3) / 8e12) if p2.get("hbm_bytes_per_launch") else None})
+    if dws_n:
+        kernels.append({"kernel": "k_dw_frag + k_wide_head_dw" if H == 256 and dtype == "bf16" else "k_dw_frag32" if H == 256 else "k_dw_stream",
+                        "ms_per_step": dws_ms / steps, "launches": dws_n})
+    if len(kernels) > 1:
+        roof["kernels"] = kernels
     if pmc.get("valu_per_mfma"):
         # the co-bound: one wave per SIMD issues the SIREN's activation / epilogue VALU through the same port as its
         # MFMAs; `issue_limited_frac` is the MFMA-peak fraction that instruction mix allows even with perfect overlap
         vpm, tpm = pmc["valu_per_mfma"], pmc.get("trans_per_mfma", 2.1)
-        roof.update({"bound": "mfma+valu_issue", "valu_per_mfma": vpm, "trans_per_mfma": tpm,
-                     "issue_limited_frac": issue_ceiling(vpm, tpm), "frac_of_issue_limit": roof["frac"] / issue_ceiling(vpm, tpm)})
+        roof.update({"bound": "mfma+valu_issue", "valu_per_mfma": vpm, "trans_per_mfma": tpm, "issue_limited_frac": issue_ceiling(vpm, tpm)})
     if stats_n:
         roof["stats_pass_avg_ms"] = stats_ms / stats_n
     rec = {"value": value, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": dtype,
@@ -468,17 +516,23 @@ def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, 
            "roofline": roof}
     if shape.get("sparsity"):
         rec["config"]["weight_sparsity"] = shape["sparsity"]
-    if world > 1 and cfg in ("c2", "film"):
-        rec["exchange"] = {"kind": "reni_allreduce_grads (C ABI, librccl)" if args.comm == "capi" else
-                           f"torch.distributed all_reduce ({torch.distributed.get_backend()})",
-                           "avg_us_on_compute_stream": comm_us}
-    if args.comm == "capi":
-        rec["config"]["exchange_step"] = "reni_allreduce_grads (C ABI, librccl)"
+    fused_dp = eng is not None and eng.comm is not None and eng._stage is not None
     if eng is not None and cfg == "c4":
         rec["config"]["step_call"] = "reni_latent_step_rows (one call: statistics pass where live + fwd + loss + bwd, Adam on the latent table)"
     if eng is not None and cfg == "c2":
-        rec["config"]["step_call"] = ("reni_train_step_rows (one call: fwd+loss+bwd, Adam, next prologue)" if eng._stage is not None
+        rec["config"]["step_call"] = ("reni_train_step_rows_dp (one call: fwd+loss+bwd, RCCL all-reduce inside, Adam, next prologue)" if fused_dp
+                                      else "reni_train_step_rows (one call: fwd+loss+bwd, Adam, next prologue)" if eng._stage is not None
+                                      else "reni_forward_loss_backward_rows + all-reduce + reni_adam_step2 (three calls)" if (world > 1 or eng.comm is not None)
                                       else "reni_forward_loss_backward_rows + reni_adam_step2")
+    if eng is not None and cfg == "film":
+        rec["config"]["step_call"] = "reni_film_model_forward_loss_backward + all-reduce + reni_adam_step"
+    if (world > 1 or (eng is not None and eng.comm is not None)) and cfg in ("c2", "film"):
+        rec["exchange"] = {"kind": ("inside reni_train_step_rows_dp (librccl, the library's communicator)" if fused_dp
+                                    else "reni_allreduce_grads (C ABI, librccl)" if eng.comm is not None
+                                    else f"torch.distributed all_reduce ({torch.distributed.get_backend()})"),
+                           "avg_us_on_compute_stream": comm_us}
+        if _COMM.get("error"):
+            rec["exchange"]["comm_fallback"] = _COMM["error"]
     return rec
 
 
@@ -542,11 +596,91 @@ def sub_record(name, args, rank, world, dev):
     return out
 
 
+LINE_MAX = 6144   # bytes of the contract line (round 5's 24 KB line did not parse on the driver's side)
+
+
+def _r(x, sig=6):
+    """floats to `sig` significant digits (the line is read by people and by a parser with a size limit)"""
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def contract_line(metric, rec, world, also, sustained, cpu):
+    """THE line: the contract's fields, the headline's roofline (with both kernels of the backward pass), `sustained`, `cpu_baseline`, and
+    for every sub-record only [value, ms_per_step, frac_step] -- the sub-records themselves are printed on the lines above it."""
+    import torch
+    cfgd = dict(rec["config"])
+    paths = cfgd.pop("paths", None)
+    if isinstance(paths, dict):   # the facts that name the code path, not the whole diagnostic record (that one is on the `also` lines)
+        cfgd["paths"] = {k: paths[k] for k in ("persistent_kernels", "dw1_kernel", "side_stream", "env_overrides", "workgroups", "error") if k in paths}
+    line = {
+        "metric": metric, "value": rec["value"], "unit": "samples/s", "n_gpus": world, "steps": rec["steps"], "warmup": rec["warmup"],
+        "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic",
+        "n_ranks_seen": torch.distributed.get_world_size() if world > 1 else 1,
+        "dist_backend": torch.distributed.get_backend() if world > 1 else None,
+        "launches_per_step": rec["launches_per_step"], "step_call": cfgd.pop("step_call", None),
+        "config": cfgd, "roofline": rec["roofline"],
+    }
+    if "exchange" in rec:
+        line["exchange"] = rec["exchange"]
+    if sustained is not None:
+        line["sustained"] = sustained
+    if cpu is not None:
+        line["cpu_baseline"] = cpu
+    if also is not None:
+        line["also"] = {k: ([v["value"], v["ms_per_step"], v["roofline"]["frac_step"]] if "error" not in v else {"error": v["error"][:80]})
+                        for k, v in also.items()}
+        line["also_fields"] = ["value (samples/s)", "ms_per_step", "roofline.frac_step"]
+    return _r(line)
+
+
+_OUT = None   # the process's REAL stdout once main() has parked fd 1 on stderr (see own_stdout)
+
+
+def own_stdout():
+    """Keep stdout for this program's lines alone: librccl prints a version banner through C stdio on fd 1 when a communicator is created
+    (seen on the GPU box: flushed at process exit, i.e. BEHIND the contract line, which must be the last line of stdout), and so may any
+    other native library.  fd 1 is duplicated for emit() and then pointed at stderr, in every rank."""
+    global _OUT
+    if _OUT is None:
+        sys.stdout.flush()
+        _OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def _say(text):
+    out = _OUT or sys.stdout
+    out.write(text + "\n")
+    out.flush()
+
+
+def emit(line, also):
+    """stdout: one `also <name> {json}` line per sub-record (full record, 5 significant digits), then THE contract line, last and alone
+    on its line, at most LINE_MAX bytes."""
+    for k, v in (also or {}).items():
+        _say("also " + k + " " + json.dumps(_r(v, 5), separators=(",", ":")))
+    out = json.dumps(line)
+    if len(out) > LINE_MAX:   # (cannot happen with today's fields: drop the optional ones rather than print a line nobody can parse)
+        for k in ("also_fields", "exchange", "sustained"):
+            line.pop(k, None)
+        line["roofline"].pop("kernels", None)
+        out = json.dumps(line)
+    assert len(out) <= LINE_MAX, len(out)
+    _say(out)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
+    own_stdout()
     import torch
     from reni_amd import dist as rdist
     try:
@@ -594,28 +728,14 @@ def main():
         # the headline's W + K steps once more, now behind ~0.3 s of load: the clocks a training run sees (side field)
         r1 = head()
         sustained = {"value": r1["value"], "ms_per_step": r1["ms_per_step"], "kernel_avg_ms": r1["roofline"]["kernel_avg_ms"],
-                     "frac": r1["roofline"]["frac"], "steps": r1["steps"], "warmup": r1["warmup"],
-                     "note": "the same W + K steps measured again behind the sub-records (GPU at sustained clocks); not `value`"}
-    line = {
-        "metric": METRIC_FWD if cfg == "c5" else METRIC_TRAIN.replace("128x256", "64x128") if cfg == "c2_curric" else METRIC_TRAIN,
-        "value": rec["value"], "unit": "samples/s", "n_gpus": world, "steps": rec["steps"], "warmup": rec["warmup"],
-        "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic",
-        "n_ranks_seen": torch.distributed.get_world_size() if world > 1 else 1,
-        "dist_backend": torch.distributed.get_backend() if world > 1 else None,
-        "launches_per_step": rec["launches_per_step"],
-        "config": rec["config"], "roofline": rec["roofline"],
-    }
-    if "exchange" in rec:
-        line["exchange"] = rec["exchange"]
-    if also is not None:
-        line["also"] = also
-    if sustained is not None:
-        line["sustained"] = sustained
+                     "frac": r1["roofline"]["frac"], "frac_step": r1["roofline"]["frac_step"], "steps": r1["steps"], "warmup": r1["warmup"],
+                     "note": "the same W+K steps again behind the sub-records (sustained clocks); not `value`"}
+    metric = METRIC_FWD if cfg == "c5" else METRIC_TRAIN.replace("128x256", "64x128") if cfg == "c2_curric" else METRIC_TRAIN
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_steps)
-        print(json.dumps(line), flush=True)
+        emit(contract_line(metric, rec, world, also, sustained,
+                           cpu_baseline(args.cpu_steps) if (world == 1 and not args.no_cpu_baseline) else None), also)
+    if _COMM.get("comm") is not None:
+        _COMM["comm"].close()
     if world > 1:
         torch.distributed.destroy_process_group()
 

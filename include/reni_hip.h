@@ -329,6 +329,8 @@ int reni_profile_read(double* total_ms, int64_t* launches, int32_t reset);
 /* The same, restricted to one kind of launch: 0 fused forward+loss+backward (what reni_profile_read returns),
  * 1 the statistics pass of RENITestLoss's cosine term, 2 plain inference (reni_forward), 3 the kernel that finishes the
  * backward pass from the g_1 stream behind the persistent training kernel (k_reni_l0_ring / k_reni_dw1_ring / k_reni_dw1),
+ * 4 the weight-gradient consumers of the fragment / operand streams (k_dw_frag, k_dw_frag32, k_dw_stream, k_wide_head_dw),
+ * 5 the data-parallel exchange inside reni_train_step_rows_dp (the skip flag's and the gradient's all-reduce, on the caller's stream),
  * -1 all of them. */
 int reni_profile_read_kind(int32_t kind, double* total_ms, int64_t* launches, int32_t reset);
 /* Shortest and longest launch of one kind among those recorded since the last reset (bench.py prints them beside the average:

@@ -79,12 +79,17 @@ class TrainEngine:
 
     def time_comm(self, on: bool):
         """Bracket every exchange step with events on the compute stream (what the step actually waits for).  time_comm(False) returns
-        the average in microseconds (None: no exchange was timed) and stops timing."""
+        the average in microseconds (None: no exchange was timed) and stops timing.  On the fused data-parallel step
+        (reni_train_step_rows_dp) the exchange is inside the library call: its duration is the library's own event pair
+        (ops.PROF_COMM, recorded while ops.profile_enable() is on), never the bracket of the whole call."""
         if on:
             self._comm_ev = []
             return None
         evs, self._comm_ev = self._comm_ev, None
         if not evs:
+            if self.comm is not None and self._stage is not None:  # the fused data-parallel step: the library's own event pairs
+                ms, n = ops.profile_read(reset=False, kind=ops.PROF_COMM)
+                return 1e3 * ms / n if n else None
             return None
         torch.cuda.synchronize(self.flat.device)
         return 1e3 * sum(a.elapsed_time(b) for a, b in evs) / len(evs)
@@ -117,18 +122,12 @@ class TrainEngine:
             self.t += 1
             _roctx.push("reni.step.fused")
             nxt = next_idx.contiguous() if next_idx is not None and int(next_idx.numel()) == shape[0] else None
-            timed = self._comm_ev is not None and self.comm is not None
-            if timed:  # (the exchange is inside the call: what is bracketed here is the whole step)
-                cur = torch.cuda.current_stream(self.flat.device)
-                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ea.record(cur)
+            # (the exchange is inside the call: nothing to bracket from here -- with ops.profile_enable() the library times its own
+            # all-reduce, ops.profile_read(kind=ops.PROF_COMM), which time_comm(False) returns for this path)
             terms, _, _ = self.plan.train_step(self.latent.data, idx.contiguous(), directions, self.flat, target, weight, self.m_dec,
                                                self.v_dec, self.m_lat, self.v_lat, self.t, self.lr, st["state"], idx_next=nxt,
                                                loss_kind=self.loss_kind, alpha=self.alpha, beta=self.beta,
                                                grad_scale=1.0 / self.world, comm=self.comm, overlap=self.overlap_dp)
-            if timed:
-                eb.record(cur)
-                self._comm_ev.append((ea, eb))
             st["expect"], st["shape"] = ((nxt.data_ptr(), nxt.numel()) if nxt is not None else None), shape
             _roctx.pop()
             return terms

@@ -533,7 +533,7 @@ def profile_enable(on: bool = True):
     _lib.check(_lib.load().reni_profile_enable(1 if on else 0))
 
 
-PROF_FWD_BWD, PROF_STATS, PROF_FWD, PROF_DW1, PROF_ALL = 0, 1, 2, 3, -1
+PROF_FWD_BWD, PROF_STATS, PROF_FWD, PROF_DW1, PROF_DWS, PROF_COMM, PROF_ALL = 0, 1, 2, 3, 4, 5, -1
 
 
 def profile_minmax(kind: int = PROF_FWD_BWD):

@@ -331,3 +331,55 @@ def test_pmc_traffic_record_belongs_to_the_committed_kernel_sources():
                    "k_reni_wide256<0>", "k_reni_wide256<1>", "k_reni_wide256<2>"):
         assert rec[kernel]["src_sha256"] == sha, f"{kernel}: PMC record is of another source state"
         assert bench.pmc_record(kernel).get("hbm_bytes_per_launch"), kernel
+
+
+def test_bench_contract_line_stays_short_and_last(capsys):
+    """round 5's 24 KB contract line (14 sub-records inside it) did not parse on the driver's side.  bench.py now prints the
+    sub-records on `also <name> {json}` lines and ends with ONE contract line of at most bench.LINE_MAX = 6144 bytes that keeps
+    [value, ms_per_step, frac_step] of each -- checked here on a synthetic record with every field at full width."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    roof = {"bound": "mfma+valu_issue", "achieved": 820.1723456789, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.3280691234, "frac_step": 0.2758141234,
+            "frac_issued": 0.2827861234, "traffic": 2924134400, "kernel": "k_reni_train_bf16<128,true,L0X>", "kernel_avg_ms": 1.336741234,
+            "kernel_min_ms": 1.281171234, "kernel_max_ms": 1.466891234, "kernel_launches": 20, "work_kernels_ms_per_step": 1.51441234, "flop_per_sample": 522784,
+            "kernels": [{"kernel": "k_reni_train_bf16<128,true,L0X>", "avg_ms": 1.336741234, "frac_issued": 0.282786, "traffic": 2924134400},
+                        {"kernel": "k_reni_l0_ring", "avg_ms": 0.1776661234, "min_ms": 0.171234, "max_ms": 0.181234, "launches": 20, "traffic": 557608960,
+                         "frac_issued": 0.4061291234, "hbm_frac": 0.3923161234}],
+            "valu_per_mfma": 7.221, "trans_per_mfma": 2.1, "issue_limited_frac": 0.6186431234}
+    paths = {"persistent_kernels": True, "dw1_kernel": "k_reni_l0_ring", "side_stream": True, "images_per_chunk": 64, "operand_stream": False,
+             "fragment_stream": "none", "env_overrides": ["RENI_NO_L0X", "RENI_FRAG_WS_CAP_MB"], "workgroups": 256}
+    rec = {"value": 1318971234.5678, "ms_per_step": 1.589991234, "steps": 20, "warmup": 5, "dtype": "bf16", "launches_per_step": 6.0,
+           "config": {"workload": "BASELINE config 2: 615-image set, 128x256 equirect, ND=36, 5x128 SIREN, SO2, tanh, AutoDecoder, RENITrainLoss; "
+                                  "full training step (fwd+loss+bwd, grad all-reduce, Adam)", "images_per_gpu_per_step": 64, "global_batch_images": 512,
+                      "directions_per_image": 32768, "parallelism": "dp8", "result_check": 0.7507611234, "paths": paths,
+                      "step_call": "reni_train_step_rows_dp (one call: fwd+loss+bwd, RCCL all-reduce inside, Adam, next prologue)"},
+           "roofline": roof,
+           "exchange": {"kind": "inside reni_train_step_rows_dp (librccl, the library's communicator)", "avg_us_on_compute_stream": 41.51234,
+                        "comm_fallback": "x" * 200}}
+    names = ("c4", "c4_dense", "c4_pixels", "c4_f32", "c5", "film", "c2_b100", "c2_curric_16x32", "c2_curric_32x64", "c2_curric_64x128", "c2_h256",
+             "c4_h256", "c4_h256_dense", "fwd_h256")
+    also = {n: {"value": 1234567890.1234, "ms_per_step": 0.4645531234, "roofline": dict(roof), "workload": "w" * 300, "paths": paths} for n in names}
+    also["film"] = {"error": "RuntimeError: " + "e" * 300}
+    sustained = {"value": 1351431234.5, "ms_per_step": 1.55181234, "kernel_avg_ms": 1.301341234, "frac": 0.3369941234, "frac_step": 0.281234, "steps": 20,
+                 "warmup": 5, "note": "the same W+K steps again behind the sub-records (sustained clocks); not `value`"}
+    cpu = {"value": 46525.81234, "unit": "samples/s", "cores": 128, "kind": "port", "port_b1": 46525.81234, "port_b4": 40755.81234, "factored": 66715.71234,
+           "factored_b1": 66715.71234, "factored_b4": 54558.61234, "sample": "s" * 260}
+    line = bench.contract_line(bench.METRIC_TRAIN, rec, 1, also, sustained, cpu)
+    bench.emit(line, also)
+    out = capsys.readouterr().out.splitlines()
+    assert len(out) == len(names) + 1 and all(ln.startswith("also ") for ln in out[:-1]) and out[-1].startswith("{")
+    assert len(out[-1]) <= bench.LINE_MAX == 6144, len(out[-1])
+    got = json.loads(out[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "sustained", "step_call", "also"):
+        assert key in got, key
+    assert got["config"]["workload"].startswith("BASELINE config 2") and "model" not in got["config"]
+    assert set(got["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "frac_step", "frac_issued", "traffic", "kernel", "kernels"}
+    assert got["also"]["c4"] == [1234570000.0, 0.464553, 0.275814] and "error" in got["also"]["film"]
+    assert got["step_call"].startswith("reni_train_step_rows_dp") and set(got["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    sub = json.loads(out[0].split(" ", 2)[2])
+    assert out[0].split(" ", 2)[1] == "c4" and sub["roofline"]["kernel"] == roof["kernel"]

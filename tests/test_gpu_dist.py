@@ -170,7 +170,12 @@ def test_two_rank_step_equals_one_rank_step_on_the_union_batch():
         assert float((Zr - lat[torch.tensor(rws, device=dev)].cpu()).abs().max()) <= 2e-5
 
 
-def _run_bench(extra_env, *args):
+LINE_MAX = 6144  # bench.py's contract line (a 24 KB line did not parse on the driver's side)
+
+
+def _run_bench(extra_env, *args, with_also=False):
+    """-> the contract line (the LAST line of stdout, alone on it, <= LINE_MAX bytes); with_also: (line, {name: sub-record}) -- the
+    sub-records are the `also <name> {json}` lines in front of it."""
     import json
     import subprocess
     import sys
@@ -179,68 +184,104 @@ def _run_bench(extra_env, *args):
     env.update(extra_env)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 alone prints, and exactly one line
-    return json.loads(lines[0])
+    out = r.stdout.splitlines()
+    lines = [ln for ln in out if ln.startswith("{")]
+    assert len(lines) == 1 and out[-1] == lines[0], r.stdout[-2000:]  # rank 0 alone prints, exactly one JSON line, and it is the last
+    assert len(lines[0]) <= LINE_MAX, len(lines[0])
+    line = json.loads(lines[0])
+    if not with_also:
+        return line
+    also = {}
+    for ln in out:
+        if ln.startswith("also "):
+            _, name, rec = ln.split(" ", 2)
+            also[name] = json.loads(rec)
+    return line, also
 
 
 def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (the driver's N > 1 form is torchrun, but the command must
     also stand alone): two rank processes are started before anything touches the GPU.  Here both share cuda:0 over
-    gloo; with two GPUs the same path runs on RCCL (next test)."""
+    gloo.  At N > 1 the step defaults to the fused data-parallel call on the library's own RCCL communicator (VERDICT r05 item 2:
+    the step N = 1 runs, with the exchange inside it); two ranks on ONE GPU is the case RCCL refuses, and then the line must say so
+    (`exchange.comm_fallback`) and name the three-call path it fell back to."""
     line = _run_bench({"RENI_SHARE_GPU": "1", "RENI_DIST_BACKEND": "gloo"}, "--gpus", "2", "--steps", "2", "--warmup", "1",
                       "--batch", "8", "--no-cpu-baseline")
     assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["dist_backend"] == "gloo"
     assert line["config"]["global_batch_images"] == 16 and line["value"] > 0
     assert line["roofline"]["kernel_launches"] == 2
+    if line["step_call"].startswith("reni_train_step_rows_dp"):      # RCCL initialised (one GPU per rank)
+        assert "comm_fallback" not in line["exchange"] and line["exchange"]["kind"].startswith("inside reni_train_step_rows_dp")
+    else:                                                             # it could not: loudly, on the line
+        assert line["exchange"]["comm_fallback"] and line["step_call"].startswith("reni_forward_loss_backward_rows + all-reduce")
+        assert line["exchange"]["kind"].startswith("torch.distributed all_reduce (gloo)")
+    # the opt-out
+    t = _run_bench({"RENI_SHARE_GPU": "1", "RENI_DIST_BACKEND": "gloo"}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+                   "--no-cpu-baseline", "--comm", "torch")
+    assert "comm_fallback" not in t["exchange"] and t["step_call"].startswith("reni_forward_loss_backward_rows + all-reduce")
 
 
 def test_bench_default_line_carries_every_baseline_config_and_the_capi_exchange():
-    """bench.py's default line: the config-2 headline plus `also` sub-records for config 4, config 5 and the FiLM step measured
-    in the same process, each with its own roofline; and `--comm capi` routes the step's exchange through
-    the C ABI's reni_allreduce_grads (here a one-rank communicator: the same call path as N > 1)."""
-    line = _run_bench({}, "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    """bench.py's default output: the config-2 headline on ONE short contract line (last), and in front of it one `also` line per
+    sub-record -- config 4, config 5, the FiLM step, the shipped batch / schedule / width -- measured in the same process, each with its
+    own roofline; the contract line keeps [value, ms_per_step, frac_step] of each.  `--comm capi` at N = 1 runs the fused data-parallel
+    step on a one-rank communicator (the same call path as N > 1)."""
+    line, also = _run_bench({}, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", with_also=True)
     curric = {"c2_curric_16x32", "c2_curric_32x64", "c2_curric_64x128"}   # configs/experiment.yaml:29-34, B = 100
-    assert set(line["also"]) == {"c4", "c4_dense", "c4_pixels", "c4_f32", "c5", "film", "c2_b100", "c2_h256", "c4_h256", "c4_h256_dense", "fwd_h256"} | curric, {k: v.get("error") for k, v in line["also"].items()}
-    assert all("error" not in v for v in line["also"].values()), {k: v.get("error") for k, v in line["also"].items()}
-    assert line["also"]["c2_b100"]["images_per_gpu_per_step"] == 100
+    assert set(also) == {"c4", "c4_dense", "c4_pixels", "c4_f32", "c5", "film", "c2_b100", "c2_h256", "c4_h256", "c4_h256_dense", "fwd_h256"} | curric, {k: v.get("error") for k, v in also.items()}
+    assert all("error" not in v for v in also.values()), {k: v.get("error") for k, v in also.items()}
+    assert set(line["also"]) == set(also)
+    for k, v in also.items():   # the contract line's triple is the sub-record's (to the printed digits)
+        val, ms, fs = line["also"][k]
+        assert abs(val - v["value"]) <= 1e-4 * val and abs(ms - v["ms_per_step"]) <= 1e-4 * ms and abs(fs - v["roofline"]["frac_step"]) <= 1e-4 * fs
+    assert also["c2_b100"]["images_per_gpu_per_step"] == 100
     # config 4 twice: with RENI_WEIGHT_SPARSE (what RENI.training_step passes with a mask; Mask-3: 148 of 256 tiles per image carry
     # weight, pixel 0 is masked -> no statistics pass) and dense; the sparse record's roofline counts visited tiles only
-    sp, de = line["also"]["c4"]["weight_sparsity"], line["also"]["c4_dense"]["weight_sparsity"]
+    sp, de = also["c4"]["weight_sparsity"], also["c4_dense"]["weight_sparsity"]
     assert sp["flag"] == "RENI_WEIGHT_SPARSE" and abs(sp["tiles_visited"] - 148 / 256) < 1e-6 and not sp["cosine_term_live"]
     assert de["flag"] == "off" and de["tiles_visited"] == 1.0 and abs(de["pixels_with_weight"] - 0.188) < 2e-3
     # (the kernels' own times, HIP events: a 0.2-0.3 ms step is host-paced on a busy host, its wall time is not a stable comparison)
-    assert line["also"]["c4"]["roofline"]["kernel_avg_ms"] < 0.8 * line["also"]["c4_dense"]["roofline"]["kernel_avg_ms"]
-    assert "stats_pass_avg_ms" in line["also"]["c4_dense"]["roofline"]
-    px = line["also"]["c4_pixels"]["weight_sparsity"]
+    assert also["c4"]["roofline"]["kernel_avg_ms"] < 0.8 * also["c4_dense"]["roofline"]["kernel_avg_ms"]
+    assert "stats_pass_avg_ms" in also["c4_dense"]["roofline"]
+    px = also["c4_pixels"]["weight_sparsity"]
     assert px["flag"] == "RENI_WEIGHT_COMPACT" and abs(px["tiles_visited"] - 49 / 256) < 1e-6
-    assert line["also"]["c4_pixels"]["roofline"]["kernel_avg_ms"] < 0.8 * line["also"]["c4"]["roofline"]["kernel_avg_ms"]
+    assert also["c4_pixels"]["roofline"]["kernel_avg_ms"] < 0.8 * also["c4"]["roofline"]["kernel_avg_ms"]
     for c, flop in (("c4", 348448), ("c4_dense", 348448), ("c4_pixels", 348448), ("c5", 177860), ("film", 424480), ("c2_h256", 2028320)):
-        r = line["also"][c]
+        r = also[c]
         assert r["value"] > 0 and r["ms_per_step"] > 0 and r["roofline"]["flop_per_sample"] == flop and r["roofline"]["kernel_avg_ms"] > 0
         assert 0 < r["roofline"]["frac_step"] <= r["roofline"]["frac"] * 1.0001 and r["ms_per_step_mean"] >= r["ms_per_step"]
+    # `frac` divides by EVERY kernel that performs the step's FLOPs (VERDICT r05): at H = 256 the chain, k_dw_frag and k_wide_head_dw
+    h256 = also["c2_h256"]["roofline"]
+    assert [k["kernel"] for k in h256["kernels"]] == ["k_reni_wide256<2>", "k_dw_frag + k_wide_head_dw"]
+    assert h256["work_kernels_ms_per_step"] > 1.3 * h256["kernel_avg_ms"] and h256["kernels"][1]["ms_per_step"] > 0
     for c in curric:
-        r = line["also"][c]
+        r = also[c]
         assert r["images_per_gpu_per_step"] == 100 and r["launches_per_step"] >= 2 and r["paths"]["env_overrides"] == []
-    assert line["also"]["c5"]["so3"]["value"] > 0            # SURVEY 8(d) C5: both invariances
-    assert line["roofline"]["flop_per_sample"] == 522784 and "also" not in line["also"]["c4"]
+    assert also["c5"]["so3"]["value"] > 0            # SURVEY 8(d) C5: both invariances
+    assert line["roofline"]["flop_per_sample"] == 522784
     # ONE definition of the headline (ADVICE r03): the contract's W + K window, first; the sustained-clock re-run is a side field
     assert line["steps"] == 3 and line["warmup"] == 1 and line["sustained"]["steps"] == 3 and "from_idle" not in line
     assert line["config"]["paths"]["dw1_kernel"] == "k_reni_l0_ring" and line["config"]["paths"]["env_overrides"] == []
-    # VERDICT r04 1(c): the three fractions side by side, the two kernels of the backward pass listed with their own times; 3: the
-    # parity-grade config 4; 5: effective vs visited samples
+    assert line["step_call"].startswith("reni_train_step_rows (one call")
+    # the fractions side by side, the two kernels of the backward pass listed with their own times; `frac` over BOTH kernels' time
     rf = line["roofline"]
     assert rf["kernel"] == "k_reni_train_bf16<128,true,L0X>" and 0 < rf["frac_step"] < rf["frac"] and rf["kernel_min_ms"] <= rf["kernel_avg_ms"] <= rf["kernel_max_ms"]
     assert [k["kernel"] for k in rf["kernels"]] == ["k_reni_train_bf16<128,true,L0X>", "k_reni_l0_ring"] and rf["kernels"][1]["avg_ms"] > 0
-    f32 = line["also"]["c4_f32"]
+    both = rf["kernel_avg_ms"] + rf["kernels"][1]["avg_ms"]
+    assert abs(rf["work_kernels_ms_per_step"] - both) <= 1e-3 * both
+    want = 522784 * 64 * 32768 / (both * 1e-3) / 1e12 / 2500.0
+    assert abs(rf["frac"] - want) <= 2e-3 * want
+    f32 = also["c4_f32"]
     assert f32["dtype"] == "f32" and f32["roofline"]["peak"] == 157.3 and f32["roofline"]["flop_per_sample"] == 348448
-    assert line["also"]["c4"]["value_kind"] == "effective_samples_per_s" and line["also"]["c4_dense"]["value_kind"] == "samples_per_s"
-    assert abs(line["also"]["c4"]["visited_samples_per_s"] - line["also"]["c4"]["value"] * 148 / 256) <= 1e-6 * line["also"]["c4"]["value"]
+    assert also["c4"]["value_kind"] == "effective_samples_per_s" and also["c4_dense"]["value_kind"] == "samples_per_s"
+    assert abs(also["c4"]["visited_samples_per_s"] - also["c4"]["value"] * 148 / 256) <= 1e-4 * also["c4"]["value"]
     assert line["launches_per_step"] == int(line["launches_per_step"]) and 2 <= line["launches_per_step"] <= 16
     forced = _run_bench({"RENI_DW1_OLD": "1"}, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-also")
     assert forced["config"]["paths"]["dw1_kernel"] == "k_reni_dw1" and forced["config"]["paths"]["env_overrides"] == ["RENI_DW1_OLD"]
     capi = _run_bench({}, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--comm", "capi")
-    assert "also" not in capi and capi["config"]["exchange_step"].startswith("reni_allreduce_grads") and capi["value"] > 0
+    assert "also" not in capi and capi["step_call"].startswith("reni_train_step_rows_dp") and capi["value"] > 0
+    ex = capi["exchange"]   # (ADVICE r05: the library's own event pair around its all-reduce, not the bracket of the whole call)
+    assert ex["kind"].startswith("inside reni_train_step_rows_dp") and 0 < ex["avg_us_on_compute_stream"] < 0.5e3 * capi["ms_per_step"]
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")
@@ -248,6 +289,7 @@ def test_bench_two_ranks_over_rccl():
     """The exchange step on the real transport: backend "nccl" (= RCCL) on two GPUs, self-launched."""
     line = _run_bench({}, "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["dist_backend"] == "nccl"
+    assert line["step_call"].startswith("reni_train_step_rows_dp") and "comm_fallback" not in line["exchange"]
     one = _run_bench({}, "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     assert line["value"] > 1.2 * one["value"]  # weak scaling: two ranks do twice the work per step
 
