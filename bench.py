@@ -661,10 +661,10 @@ def _say(text):
 
 
 def emit(line, also):
-    """stdout: one `also <name> {json}` line per sub-record (full record, 5 significant digits), then THE contract line, last and alone
+    """stdout: one `also <name> {json}` line per sub-record (full record, 7 significant digits), then THE contract line, last and alone
     on its line, at most LINE_MAX bytes."""
     for k, v in (also or {}).items():
-        _say("also " + k + " " + json.dumps(_r(v, 5), separators=(",", ":")))
+        _say("also " + k + " " + json.dumps(_r(v, 7), separators=(",", ":")))
     out = json.dumps(line)
     if len(out) > LINE_MAX:   # (cannot happen with today's fields: drop the optional ones rather than print a line nobody can parse)
         for k in ("also_fields", "exchange", "sustained"):

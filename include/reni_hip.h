@@ -289,7 +289,11 @@ int reni_latent_step_rows(const reni_plan* plan, int64_t B, int64_t P, float* Z_
  *                                            optionally reports what the lists hold (one synchronisation);
  *   reni_latent_step_rows_cached(..., lists) reni_latent_step_rows with the list-building launches left out: the same kernels on the
  *                                            same lists, results BIT-EQUAL to the rebuilt-every-call entry point.
- * The caller rebuilds the lists whenever the weight, B or P changes; `flags` of the step = `flags` of the build. */
+ * The caller rebuilds the lists whenever the weight, B or P changes; `flags` of the step = `flags` of the build.
+ * The library remembers, on the host, which buffers reni_weight_lists_build filled for which (B, P, mode) -- the last 64 builds --
+ * and reni_latent_step_rows_cached returns RENI_EINVAL for a buffer it has no record of or that was built for another shape or mode
+ * (the lists' layout depends on B and P: read at another shape they would be left).  What the record cannot see is a weight that
+ * changed under unchanged lists. */
 size_t reni_weight_lists_bytes(int64_t B, int64_t P);
 /* summary_host (optional, 3 ints): after ONE stream synchronisation -- tiles the main pass will visit, tiles of the statistics pass,
  * images whose cosine term is live (0: the steps may carry RENI_WEIGHT_COS_CONSTANT). */

@@ -241,7 +241,14 @@ class Plan:
         """The tile / pixel lists of a masked weight (reni_weight_lists_build), built ONCE per (weight tensor, its version counter,
         shape, strides, mode) and kept on the plan: the inpainting mask of a FIT_LATENT run does not change over its epochs.
         weight: the [B, P, 3] (expanded) view the step passes; mode: _lib.WEIGHT_SPARSE or _lib.WEIGHT_COMPACT."""
-        key = (weight.data_ptr(), weight._version, tuple(weight.shape), tuple(weight.stride()), int(B), int(P), int(mode), weight.device.index)
+        # CAVEAT (ADVICE r05): the key sees in-place writes only through torch's version counter -- a write through `weight.data`, a
+        # custom kernel or ctypes does not bump it.  Whoever changes the mask that way calls invalidate_weight_lists() (or passes
+        # cache_lists=False to latent_step).  Inference tensors have no version counter: they are never cached (-> None).
+        try:
+            version = weight._version
+        except RuntimeError:
+            return None
+        key = (weight.data_ptr(), version, tuple(weight.shape), tuple(weight.stride()), int(B), int(P), int(mode), weight.device.index)
         cache = self.__dict__.setdefault("_wlists", {})
         hit = cache.get("key") == key
         if not hit:
@@ -259,6 +266,11 @@ class Plan:
             cache.update(key=key, buf=buf, ptr=lp, weight=weight, cos_constant=summary[2] == 0,   # (the weight is kept alive: its
                          summary=tuple(summary))                                                  #  data_ptr is part of the key)
         return cache["ptr"], (_lib.WEIGHT_COS_CONSTANT if cache["cos_constant"] else 0)
+
+    def invalidate_weight_lists(self):
+        """Forget the cached tile / pixel lists: the next latent_step(sparse_weight=...) rebuilds them from the weight it is given.  To be
+        called after a write into the weight tensor that torch's version counter cannot see (``weight.data``, a custom kernel, ctypes)."""
+        self.__dict__.pop("_wlists", None)
 
     def latent_step(self, Z_table, idx, D, params, target, weight, m_lat, v_lat, step, lr, loss_kind="test", alpha=0.0, beta=0.0,
                     betas=(0.9, 0.999), eps=1e-8, sparse_weight=False, cache_lists=True):
@@ -298,7 +310,11 @@ class Plan:
             chunked = cc[(B, P)]
         if flags and cache_lists and not chunked:
             # the lists from the plan's cache (built once per mask: reni_weight_lists_build), the step without its list-building launches
-            lptr, extra = self.weight_lists(B, P, weight, flags)
+            wl = self.weight_lists(B, P, weight, flags)
+        else:
+            wl = None
+        if wl is not None:
+            lptr, extra = wl
             _lib.check(self.lib.reni_latent_step_rows_cached(*head[:-1], flags | extra, lptr, *tail))
         else:
             _lib.check(self.lib.reni_latent_step_rows(*head, *tail))

@@ -182,7 +182,8 @@ int main(void) {
   EXPECT(reni_latent_step_rows_cached(p, 2, 256, fake, 10, (const int64_t*)fake, fake, 0, fake, fake, st, fake, st, RENI_LOSS_TEST, 1e-7f, 1e-4f,
                                       0, ws, fake, fake, 1e-1f, .9f, .999f, 1e-8f, 1, terms, fake, ws, 16, NULL), RENI_EINVAL);
   EXPECT(reni_latent_step_rows_cached(p, 2, 256, fake, 10, (const int64_t*)fake, fake, 0, fake, fake, st, fake, st, RENI_LOSS_TEST, 1e-7f, 1e-4f,
-                                      RENI_WEIGHT_COMPACT, ws, fake, fake, 1e-1f, .9f, .999f, 1e-8f, 1, terms, fake, ws, 16, NULL), RENI_EWORKSPACE);
+                                      RENI_WEIGHT_COMPACT, ws, fake, fake, 1e-1f, .9f, .999f, 1e-8f, 1, terms, fake, ws, 16, NULL), RENI_EINVAL);
+  /* (^ a lists buffer no reni_weight_lists_build is on record for: refused before anything reads it -- round 6) */
   /* reni_latent_step_rows: NULL idx / optimiser state, step 0, flags other than the RENI_WEIGHT_* bits, then the workspace check */
   EXPECT(reni_latent_step_rows(p, 2, 256, fake, 10, NULL, fake, 0, fake, fake, st, fake, st, RENI_LOSS_TEST, 1e-7f, 1e-4f, 0, fake, fake,
                                1e-1f, .9f, .999f, 1e-8f, 1, terms, fake, ws, 16, NULL), RENI_EINVAL);

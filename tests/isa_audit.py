@@ -154,6 +154,88 @@ def valu_to_mfma(text, need=2):
     return bad
 
 
+# transcendental VALU opcodes of gfx950 (LLVM: SIInstrFlags::TRANS): a NON-transcendental VALU that reads such a result needs one wait
+# state in between (GCNHazardRecognizer: hasTransForwardingHazard, TransDefWaitstates = 1).  hipcc pads its own code; it does not look
+# into an asm statement, nor across the boundary between an asm statement and its own code -- where the kernels' sine / cosine epilogues sit.
+TRANS = re.compile(r"v_(exp|log|rcp|rcp_iflag|rsq|sqrt|sin|cos)(_legacy)?_(f32|f16|bf16)(_e32|_e64|_sdwa|_dpp)?$")
+
+
+def trans_to_valu(text, need=1):
+    """-> [(function, line of the transcendental, line of the reader, states between)] for every non-transcendental VALU (or MFMA) that
+    reads a transcendental's destination VGPR with fewer than `need` wait states between them, on any control-flow path (`s_nop N` counts
+    N + 1, any other instruction 1, a taken branch 0)."""
+    labels, prog, fnames = parse(text)
+    fk = sorted(fnames)
+
+    def fn(k):
+        j = bisect.bisect_right(fk, k) - 1
+        return fnames[fk[j]] if j >= 0 else "?"
+
+    bad = []
+    for k, (ln, t) in enumerate(prog):
+        parts = t.split(None, 1)
+        if not TRANS.match(parts[0]) or len(parts) < 2:
+            continue
+        dst = {r for r in _regs(parts[1].split(",")[0]) if r[0] == "v"}
+        if not dst:
+            continue
+        stack, seen = [(k + 1, 0)], set()
+        while stack:
+            pc, st = stack.pop()
+            while pc < len(prog) and st < need:
+                if (pc, st) in seen:
+                    break
+                seen.add((pc, st))
+                l2, t2 = prog[pc]
+                p2 = t2.split(None, 1)
+                op = p2[0]
+                if op == "s_endpgm":
+                    break
+                if op == "s_branch" or op.startswith("s_cbranch"):
+                    tgt = t2.split()[1]
+                    if tgt in labels:
+                        stack.append((labels[tgt], st))
+                    if op == "s_branch":
+                        break
+                    pc += 1
+                    st += 1
+                    continue
+                if (op.startswith("v_") and len(p2) > 1):
+                    ops = p2[1].split(",")
+                    srcs = set()
+                    for o in ops[1:]:  # (every operand behind the destination; an MFMA: SrcA, SrcB, SrcC)
+                        srcs |= _regs(o)
+                    if srcs & dst and not TRANS.match(op):
+                        bad.append((fn(k), ln, l2, st))
+                        break
+                    if _regs(ops[0]) & dst and not op.startswith("v_cmp"):
+                        break  # overwritten: the hazard ends here
+                st += _states(t2)
+                pc += 1
+    return bad
+
+
+def sdwa_partial_dst(text):
+    """asm SDWA / op_sel instructions that write PART of a dword (dst_sel other than DWORD): gfx950's dst-forwarding hazard then needs a
+    wait state in front of a VALU reading the register, which hipcc inserts for its own code only -> [(function, line, text)] inside
+    ASMSTART .. ASMEND blocks."""
+    out, in_asm, cur = [], False, "?"
+    for i, line in enumerate(text.split("\n")):
+        m = re.match(r"^(_Z[\w$]+):", line)
+        if m:
+            cur = m.group(1)
+        if "ASMSTART" in line:
+            in_asm = True
+        elif "ASMEND" in line:
+            in_asm = False
+        elif in_asm:
+            code = line.split(";")[0]
+            m = re.search(r"dst_sel:(\w+)", code)
+            if m and m.group(1) != "DWORD":
+                out.append((cur, i + 1, code.strip()))
+    return out
+
+
 def violations(text, skip=("k_probe",)):
     bad = []
     for (f, kind), v in audit(text).items():
@@ -171,3 +253,7 @@ if __name__ == "__main__":
         print("VIOLATION", b)
     for b in valu_to_mfma(txt):
         print("VALU->MFMA", b)
+    for b in trans_to_valu(txt):
+        print("TRANS->VALU", b)
+    for b in sdwa_partial_dst(txt):
+        print("SDWA partial dst in asm", b)

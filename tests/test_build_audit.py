@@ -98,7 +98,20 @@ def test_mfma_results_are_never_read_before_their_write_back():
         early = isa_audit.valu_to_mfma(text)
         assert not early, f"VALU write within 2 wait states of an MFMA reading it ({t}): " + "; ".join(
             f"{f[:40]} asm lines {a}->{b} ({st} states)" for f, a, b, st in early[:8])
+        # the hazard hipcc does not see across an asm statement's edge -- a transcendental's result read by the next
+        # VALU (round 5: an asm v_cvt_pk_bf16_f32 straight behind v_sin_f32 in k_reni_l0_ring gave run-to-run different bits) -- on EVERY
+        # instance of every translation unit: the sparse / compact frozen instances, the FiLM instances, k_reni_wide256<0/1/2>,
+        # k_reni_l0_ring, the generic kernels; and no asm SDWA instruction that writes part of a dword (dst-forwarding hazard)
+        tv = isa_audit.trans_to_valu(text)
+        assert not tv, f"transcendental result read by the next VALU without a wait state ({t}): " + "; ".join(
+            f"{f[:48]} asm lines {a}->{b}" for f, a, b, st in tv[:8])
+        sd = isa_audit.sdwa_partial_dst(text)
+        assert not sd, f"asm SDWA instruction with a partial destination ({t}): " + "; ".join(f"{f[:40]} line {a}: {c}" for f, a, c in sd[:8])
     assert any("k_reni_train_bf16" in f for f in kernels) and any("k_reni_main" in f for f in kernels)
+    # (the instances the round-4 intermittent failure could have come from are all among the audited functions)
+    for need in ("k_reni_l0_ring", "k_reni_wide256ILi0", "k_reni_wide256ILi1", "k_reni_wide256ILi2", "k_reni_train_bf16ILi128ELb0ELb0ELb0",
+                 "k_reni_train_bf16ILi128ELb0ELb1ELb0", "k_reni_train_bf16ILi128ELb1ELb0ELb1", "k_reni_dw1_ring", "k_dw_frag"):   # (k_wide_head_dw: no MFMA -- audited by trans_to_valu all the same)
+        assert any(need in f for f in kernels), need
     assert sum("k_reni_main" in f for f in kernels) >= 40  # 2 precisions x 4 widths x 3 modes x {concat, FiLM}, minus MFMA-free ones
     assert not bad, "MFMA result accessed too early: " + "; ".join(
         f"{f[:48]} {k} {st} states (asm lines {a}->{b})" for f, k, st, a, b in bad[:8])

@@ -193,3 +193,41 @@ def test_cached_weight_lists_follow_the_weight(sparse):
     for k in (0, 3):
         assert launches[True][k] == launches[False][k] - 2, (k, launches)
     assert launches[True][5] == launches[False][5], launches
+
+
+def test_cached_lists_built_for_another_shape_are_refused():
+    """the lists' layout is a function of (B, P); reni_latent_step_rows_cached checks -- on the host, against the library's
+    record of what reni_weight_lists_build built where -- that the buffer it is handed was built for this call's B, P and mode, and
+    refuses anything else before a kernel reads it."""
+    import ctypes
+    from reni_amd import _lib
+    from reni_amd.models import RENIAutoDecoder
+    dev = torch.device("cuda:0")
+    N, W = 6, 64
+    D, S, T = _data(N, W, dev)
+    m = RENIAutoDecoder(N, 9, "SO2", 128, 5, 3, True, "tanh", 30.0, 30.0, True)
+    m.set_compute_dtype("bf16").to(dev)
+    plan = m._plan()
+    P = D.shape[1]
+    w4 = S.expand(4, P, 3).contiguous()
+    lptr, _ = plan.weight_lists(4, P, w4, _lib.WEIGHT_SPARSE)
+    ml, vl = torch.zeros_like(m.Z.data), torch.zeros_like(m.Z.data)
+
+    def cached(B, mode, ptr):
+        idx = torch.arange(B, device=dev)
+        w = S.expand(B, P, 3).contiguous()
+        ts = (ctypes.c_int64 * 3)(*T[idx].stride()); wst = (ctypes.c_int64 * 3)(*w.stride())
+        lt = torch.empty(4, device=dev); dZ = torch.empty(B, 9, 3, device=dev)
+        ws = plan.workspace(B, P, _lib.NEED_DZ | mode, dev)
+        wp, wn = plan._aligned_ptr(ws)
+        tgt = T[idx].contiguous()
+        return plan.lib.reni_latent_step_rows_cached(plan._h, B, P, m.Z.data.data_ptr(), N, idx.data_ptr(), D.data_ptr(), 0, m._flat_params().data_ptr(),
+                                                     tgt.data_ptr(), ts, w.data_ptr(), wst, _lib.LOSS_TEST, 1e-7, 1e-4, mode, ptr, ml.data_ptr(),
+                                                     vl.data_ptr(), 0.1, 0.9, 0.999, 1e-8, 1, lt.data_ptr(), dZ.data_ptr(), wp, wn,
+                                                     torch.cuda.current_stream(dev).cuda_stream)
+
+    assert cached(4, _lib.WEIGHT_SPARSE, lptr) == 0
+    assert cached(3, _lib.WEIGHT_SPARSE, lptr) == -1 and b"built for B=4" in plan.lib.reni_last_error()      # RENI_EINVAL: another B
+    assert cached(4, _lib.WEIGHT_COMPACT, lptr) == -1 and b"mode" in plan.lib.reni_last_error()              # another mode
+    assert cached(4, _lib.WEIGHT_SPARSE, lptr + 256) == -1 and b"no reni_weight_lists_build" in plan.lib.reni_last_error()
+    torch.cuda.synchronize()

@@ -17,6 +17,8 @@ fp32 gradient than the reference's own bf16 gradient at every checkpoint (assert
 region (|dZ| falls 13-fold by step 100), where the gradient is a small difference of large per-pixel terms and a bf16 forward pass leaves
 22 % (HIP) / 71 % (autocast) relative error in it, and Adam's normalisation turns sign flips of near-zero components into full-size
 steps.  The loss the loop is run for stays within 0.75 % of the reference's curve.  Latent-level fidelity needs the fp32 kernels.
+(Round 6: with the frozen-decoder calls' W^T images made exact multiples of the forward images the bf16 kernels end at cosine 0.76 and
+their completed maps at 48.9 / 47.6 dB -- ahead of the autocast run on both counts; FINDING 2 in test_c4_latent_trajectory_bf16_g14.)
 """
 import numpy as np
 import pytest
@@ -45,7 +47,7 @@ def _band(ref, autocast):
     return min(max(FLOOR, 3.0 * dev_ac), CAP)
 
 
-def _run_g14(dtype, dev, sparse=False):
+def _run_g14(dtype, dev, sparse=False, imgs=None):
     from reni_amd.engine import TrainEngine
     from reni_amd.models import RENIAutoDecoder
     from reni_amd.utils import get_directions, get_sineweight
@@ -57,7 +59,7 @@ def _run_g14(dtype, dev, sparse=False):
     m.set_compute_dtype(dtype).to(dev)
     D = get_directions(W).to(dev)
     S = (get_sineweight(W) * torch.from_numpy(g["mask"])).to(dev)
-    imgs = torch.from_numpy(g["imgs"]).to(dev)
+    imgs = (torch.from_numpy(g["imgs"]) if imgs is None else imgs).to(dev)   # (imgs: the perturbed targets of the ensemble test)
     P = D.shape[1]
     eng = TrainEngine(m, lr=float(g["lr"]), loss_kind="test", alpha=float(g["alpha"]), beta=float(g["beta"]), sparse_weight=sparse)
     idx = torch.arange(N, device=dev)
@@ -115,23 +117,60 @@ def test_c4_latent_trajectory_bf16_g14():
     assert (rel <= band).all(), (rel, band)
     # the loss at the end is what the inpainting loop is run for: within 1 % of the reference's
     assert abs(terms[-1, 0] - ref[-1, 0]) <= 1e-2 * ref[-1, 0]
-    # the latents: pinned while the gradient is well-conditioned (20 steps); behind that see FINDING in the module docstring -- the
-    # cosines are printed, and what is ASSERTED is the loop's product, in image space: the completed maps against
-    # the reference's fp32 result over the MASKED-OUT pixels (what inpainting is for) and over the kept ones, no worse than what the
-    # reference's own code does under autocast-bf16, less 1 dB
+    # the latents: pinned while the gradient is well-conditioned (20 steps); behind that see FINDING in the module docstring.  Kept as a
+    # regression guard: at 100 and 200 steps at least half the cosine the reference's own autocast run keeps -- and, since
+    # round 6 (the W^T images of a frozen-decoder call are exact multiples of the forward images: FINDING 2 below), MORE than it keeps
+    # at the end (measured 0.759 against autocast's 0.664; round 5: 0.485)
     assert cos[20] >= 0.98, cos
+    assert cos[100] >= 0.5 * cos_ac[100] and cos[200] >= 0.5 * cos_ac[200], (cos, cos_ac)
+    assert cos[200] >= cos_ac[200], (cos, cos_ac)
+    # What is ASSERTED about the loop's product: the completed maps against the reference's fp32
+    # result over the MASKED-OUT pixels (what inpainting is for) and over the kept ones, no worse than what the reference's own code
+    # does under autocast-bf16, less 1 dB.
+    # FINDING 2 (round 6, profiles/r06_trajectory.md).  Round 5's kernels missed that by 4-5 dB (43.6 dB against 48.1 dB) although their
+    # per-step gradient was 3 x closer to the fp32 gradient than autocast's.  A perturbation ensemble (test below) showed the gap was
+    # systematic, not the loop's chaos (43.57 +- 0.15 dB over seven runs), and the generic bf16 kernel -- same per-step gradient error --
+    # ended at 51.1 dB.  The cause: the persistent kernels' W^T images were rounded independently of the forward images
+    # (bf16(omega W) against bf16(W omega / 2 pi): the ratio 2 pi is no power of two), so the backward pass was the gradient of another
+    # network than the one the forward pass evaluates, and the loop's fixed point -- where THAT gradient vanishes -- is not a minimum of
+    # the loss the forward pass measures: a first-order image error.  With the W^T images 8 x the forward images (and the rest of the
+    # factor on d loss / d y): 48.9 / 47.6 dB.  None of the approximations VERDICT r05 listed (fp16 phase stash, v_cos_f16, unreduced
+    # v_sin_f32 arguments) moved the result by more than 1.3 dB in either direction (RENI_ABL 1, 2, 4 in reni_dev_common.inc).
     masked_out = (g["mask"].reshape(-1, 3) == 0).all(1)
     ref_img, ac_img = g["img_after_200"], g["img_after_200_autocast_bf16"].astype(np.float32)
-    # FINDING (round 5, profiles/r05_trajectory.md): the bf16 kernels' completed maps are 4-5 dB further from the reference's fp32 maps
-    # than the reference's own autocast run is (43.6 dB against 48.1 dB over the masked-out pixels) -- torch.autocast keeps activations,
-    # sine arguments and every accumulation in fp32 and rounds only the linear layers' operands, the kernels carry bf16 activations
-    # and fp16 phases between layers.  VERDICT r04 asked for "no worse than autocast - 1 dB": NOT met.  What is asserted is what
-    # holds: within 6 dB of the autocast run and above 40 dB (an rms error under 1 % of the value range) in both regions; the fp32
-    # kernels (bench.py's c4_f32 record) are the parity-grade arithmetic for this loop, see INTEGRATION.md section 2a.
     for name, sel in (("masked-out", masked_out), ("kept", ~masked_out)):
         p_hip, p_ac = _psnr(snaps["img"], ref_img, sel), _psnr(ac_img, ref_img, sel)
         print(f"G14 bf16: final image PSNR vs the reference's fp32 image, {name} pixels: HIP {p_hip:.2f} dB, reference under autocast {p_ac:.2f} dB")
-        assert p_hip >= p_ac - 6.0 and p_hip >= 40.0, (name, p_hip, p_ac)
+        assert p_hip >= p_ac - 1.0 and p_hip >= 46.0, (name, p_hip, p_ac)
+
+
+def test_c4_latent_trajectory_bf16_ensemble_g14():
+    """One trajectory is one draw.  tests/golden/g14_ensemble.npz (make_g14_ensemble.py) holds the reference's own code -- fp32 and under
+    autocast(bfloat16) -- on six copies of G14 whose TARGETS carry 1e-6 x N(0, 1) noise: the spread of its final-image PSNR (against
+    the unperturbed fp32 run) is what the loop does to a perturbation no arithmetic avoids (autocast: 46.4 .. 48.6 dB masked-out,
+    44.6 .. 47.8 dB kept).  The bf16 kernels on the same six targets (rebuilt from the seeds): the MEAN over the ensemble no worse than
+    autocast's mean less 1 dB, every member above 45 dB, and the final latents closer to the reference's than autocast's are."""
+    dev = torch.device("cuda:0")
+    ens = load_golden("g14_ensemble.npz")
+    g = load_golden("g14_c4_trajectory.npz")
+    rows = ens["rows"]
+    masked_out = (g["mask"].reshape(-1, 3) == 0).all(1)
+    imgs0 = torch.from_numpy(g["imgs"])
+    got = []
+    for r in rows:
+        seed = int(r[0])
+        imgs = imgs0 + float(ens["noise"]) * torch.randn(imgs0.shape, generator=torch.Generator().manual_seed(int(ens["seed_base"]) + seed))
+        _, _, snaps = _run_g14("bf16", dev, imgs=imgs)
+        got.append((_psnr(snaps["img"], g["img_after_200"], masked_out), _psnr(snaps["img"], g["img_after_200"], ~masked_out),
+                    _cos(snaps[200], g["Z_after_200"])))
+        print("G14 ensemble seed %d: HIP bf16 %.2f / %.2f dB cos %.3f | reference fp32 %.2f / %.2f dB | autocast-bf16 %.2f / %.2f dB cos %.3f"
+              % (seed, *got[-1], r[1], r[2], r[4], r[5], r[6]))
+    got = np.array(got)
+    print("G14 ensemble means: HIP bf16 %.2f / %.2f dB cos %.3f | autocast-bf16 %.2f / %.2f dB cos %.3f"
+          % (got[:, 0].mean(), got[:, 1].mean(), got[:, 2].mean(), rows[:, 4].mean(), rows[:, 5].mean(), rows[:, 6].mean()))
+    assert got[:, 0].mean() >= rows[:, 4].mean() - 1.0 and got[:, 1].mean() >= rows[:, 5].mean() - 1.0, (got.mean(0), rows.mean(0))
+    assert got[:, :2].min() >= 45.0, got
+    assert got[:, 2].mean() >= rows[:, 6].mean(), (got[:, 2], rows[:, 6])
 
 
 def test_c4_latent_trajectory_with_sparse_weight_is_the_same_trajectory_g14():
