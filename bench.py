@@ -246,8 +246,22 @@ def _rccl_comm(args, rank, world, dev):
         comm, err = None, None
         try:
             comm = rdist.RcclComm(rank, world)
+            # one small all-reduce through it, checked against the sum every rank can compute: a communicator that comes up but does
+            # not reduce (or a library that is not the one torch talks to) must not reach the timed steps
+            probe = torch.full((1024,), float(rank + 1), device=dev)
+            comm.allreduce_(probe, 1.0)
+            torch.cuda.synchronize(dev)
+            want = world * (world + 1) / 2.0
+            if not bool((probe == want).all()):
+                raise RuntimeError(f"probe all-reduce gave {float(probe[0])}, expected {want}")
         except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"[:200]
+            if comm is not None:
+                try:
+                    comm.close()
+                except Exception:  # noqa: BLE001
+                    pass
+                comm = None
         if world > 1:
             ok = torch.tensor([0 if comm is None else 1], device=dev)
             torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
