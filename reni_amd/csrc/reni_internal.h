@@ -14,9 +14,10 @@ struct MainArgs {
   int L, last_linear, act, loss_kind, need_dw;
   int dbg;  // ablation mask for profiling experiments (RENI_DEBUG_MASK); 0 in production
   float w_first, w_hidden, beta;
-  // Frozen-decoder calls on the persistent bf16 kernels (round 6): the W^T images are EXACT power-of-two multiples (x 8) of the forward
-  // images' rounded weights -- the backward pass is the transpose of the very network the forward pass evaluates -- and the constant
-  // that is then missing from the gradient, (2 pi)^L omega_first / 8^(L+1), rides on d loss / d y.  1 everywhere else.
+  // Concat calls on the persistent bf16 kernels (round 6): the W^T images are EXACT power-of-two
+  // multiples (x 8) of the forward images' rounded weights -- the backward pass is the transpose of the very network the forward pass
+  // evaluates -- and the constant that is then missing from the gradient, (2 pi)^L omega_first / 8^(L+1), rides on d loss / d y (the
+  // weight gradients' per-layer constants are multiplied back where their partials are summed: reni::LayerScale).  1 everywhere else.
   float gy_scale;
   // inputs
   const float* Z;

@@ -169,10 +169,12 @@ def test_cosine_loss_on_the_persistent_kernels(dev, L):
             gp = unflatten(spec, dp.cpu())
             for k in gp:
                 t = tol["grad"]
-                if gp[k].numel() <= 3:
+                if gp[k].numel() <= 3 or k == "net.%d.weight" % (L + 1):
                     # The head bias gradient is three sums of signed per-sample terms that largely cancel, so the bf16 error of
                     # the OUTPUTS shows in it magnified (the kernel sums the terms themselves in fp32).  Its bound is what the
                     # reference's own arithmetic gives on this problem when its linear layers run in bf16 (autocast), x 1.5.
+                    # (Round 6: the head WEIGHT gradient -- 3 x 128 sums of the same signed terms times bf16 activations -- gets the
+                    # same derived bound: at L = 4 it sits at 2.8-3.1e-2 depending on the rounding realisation of d loss / d y.)
                     with torch.autocast("cpu", dtype=torch.bfloat16):
                         rb = O.fwd_loss_bwd(spec, params, Z, D.expand(B, P, 3), T, Wm.expand(B, P, 3), "test", 1e-3, 1e-1)
                     # (capped: where the reference's own bf16 run is off by more than 10 %, 1.5 x that asserts nothing -- ADVICE r03)
