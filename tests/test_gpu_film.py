@@ -301,3 +301,35 @@ def test_film_train_engine_step_equals_autograd_plus_adam(dev):
     assert set(sa) == set(sb)
     for k in sa:
         assert float((sa[k] - sb[k]).abs().max()) <= 2e-6 + 1e-4 * float(sb[k].abs().max()) * 1e-2, k
+
+
+@pytest.mark.parametrize("B,W,nF", [(4, 256, 5), (3, 64, 5), (5, 32, 3), (2, 128, 6)])
+def test_film_forward_at_the_shipped_width_on_the_wide_kernel(dev, monkeypatch, B, W, nF):
+    """Round 6 (second half): the forward pass of the reference's DEFAULT model at its shipped width -- FiLM, 256
+    features (configs/default.py:9,13; RENI.py:508-519, 565-586) -- runs on k_reni_wide256<0, FILM>: per-image (freq, phase) tables in
+    LDS, several images per call (the tables change inside a workgroup's walk), odd pair counts, 2..5 hidden FiLM layers.  Against the
+    generic kernel (RENI_NO_PERSIST: other bits, same arithmetic class) and the fp32 kernels, whose parity with the reference is pinned by
+    G11: the two bf16 kernels must be as close to fp32 as each other."""
+    from reni_amd.film import RENIAutoDecoderFiLM
+    from reni_amd.utils import get_directions
+    D = get_directions(W).to(dev)
+    outs = {}
+    for name, env, dtype in (("wide", None, "bf16"), ("generic", "1", "bf16"), ("f32", None, "f32")):
+        if env:
+            monkeypatch.setenv("RENI_NO_PERSIST", env)
+        else:
+            monkeypatch.delenv("RENI_NO_PERSIST", raising=False)
+        torch.manual_seed(3)
+        m = RENIAutoDecoderFiLM(B, 49, "SO2", 256, nF, 256, 3, 3, "tanh", True)
+        with torch.no_grad():
+            m.Z.normal_(generator=torch.Generator().manual_seed(4))
+        m.set_compute_dtype(dtype).to(dev)
+        with torch.no_grad():
+            outs[name] = m(torch.arange(B, device=dev), D).float().cpu()
+    monkeypatch.delenv("RENI_NO_PERSIST", raising=False)
+    assert torch.isfinite(outs["wide"]).all()
+    assert not torch.equal(outs["wide"], outs["generic"]), "the persistent instance did not run (bit-identical to RENI_NO_PERSIST)"
+    e_w = float((outs["wide"] - outs["f32"]).abs().max()); e_g = float((outs["generic"] - outs["f32"]).abs().max())
+    r_w = float((outs["wide"] - outs["f32"]).pow(2).mean().sqrt()); r_g = float((outs["generic"] - outs["f32"]).pow(2).mean().sqrt())
+    assert e_w <= 5e-3 and e_w <= 1.5 * e_g + 2e-4 and r_w <= 1.2 * r_g + 2e-5, (e_w, e_g, r_w, r_g)
+    assert float((outs["wide"] - outs["generic"]).abs().max()) <= 2.5e-3
