@@ -29,15 +29,17 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VM
 done
 python3 profiles/make_pmc_traffic.py $O/pmc_counters.md $O/pmc_instruction_mix.md > $O/pmc_traffic.json 2>> $O/bench.err
 cp $O/pmc_traffic.json profiles/pmc_traffic.json   # (so that the bench lines below carry the traffic of THIS source state)
+# (round 6: bench.py prints `also <name> {json}` lines and then ONE contract line: the whole stdout is kept as .txt, the line as .json)
+run_bench() { out=$1; shift; python bench.py "$@" > $O/$out.txt 2>> $O/bench.err; tail -n 1 $O/$out.txt > $O/$out.json; cut -c1-200 $O/$out.json; }
 for c in c2 c4 c5 film c2_curric c2_h256; do
   X="--config $c --no-cpu-baseline"; [ $c = c2 ] && X="--steps 20 --warmup 5"   # (c2: exactly the driver's command)
-  python bench.py $X > $O/bench_$c.json 2>> $O/bench.err; cut -c1-200 $O/bench_$c.json
+  run_bench bench_$c $X
 done
-python bench.py --config c4 --dense --no-cpu-baseline > $O/bench_c4_dense.json 2>> $O/bench.err    # RENI_WEIGHT_SPARSE off
-python bench.py --config c4 --pixels --no-cpu-baseline > $O/bench_c4_pixels.json 2>> $O/bench.err  # RENI_WEIGHT_COMPACT
-python bench.py --config c4 --hidden 256 --no-cpu-baseline > $O/bench_c4_h256.json 2>> $O/bench.err
-python bench.py --config c4 --hidden 256 --dense --no-cpu-baseline > $O/bench_c4_h256_dense.json 2>> $O/bench.err
-python bench.py --config c5 --hidden 256 --no-cpu-baseline > $O/bench_fwd_h256.json 2>> $O/bench.err
+run_bench bench_c4_dense --config c4 --dense --no-cpu-baseline        # RENI_WEIGHT_SPARSE off
+run_bench bench_c4_pixels --config c4 --pixels --no-cpu-baseline      # RENI_WEIGHT_COMPACT
+run_bench bench_c4_h256 --config c4 --hidden 256 --no-cpu-baseline
+run_bench bench_c4_h256_dense --config c4 --hidden 256 --dense --no-cpu-baseline
+run_bench bench_fwd_h256 --config c5 --hidden 256 --no-cpu-baseline
 for c in c2 c4 c5 film c2_h256; do
   # c2: the DEFAULT command as the driver runs it (the headline's 5 + 20 steps first, the sub-records, the same steps again): the
   # summary's last two lines are the averages of the headline's and of the sustained window's 20 timed launches
