@@ -26,9 +26,9 @@ names = {"k_reni_train_bf16<128, true, false, false, true, true>": "k_reni_train
          "k_reni_train_bf16<128, false, true, false, false, false>": "k_reni_train_bf16<128,false,true>",
          "k_reni_train_bf16<128, true, false, true, true, false>": "k_reni_train_bf16<128,true,false,true>",   # (FiLM: its SPEC instance)
          "k_reni_main<reni::PolBF16, 256, 2, false>": "k_reni_main<bf16,H=256,FWD_BWD>",                 # (c2_h256: the shipped width)
-         "k_reni_wide256<2>": "k_reni_wide256<2>",                                                         # (c2_h256 from round 5: the training form)
-         "k_reni_wide256<1>": "k_reni_wide256<1>",                                                         # (c4 at H = 256: frozen decoder)
-         "k_reni_wide256<0>": "k_reni_wide256<0>",                                                         # (forward / statistics at H = 256)
+         "k_reni_wide256<2, false>": "k_reni_wide256<2>",                                                  # (c2_h256 from round 5: the training form)
+         "k_reni_wide256<1, false>": "k_reni_wide256<1>",                                                  # (c4 at H = 256: frozen decoder)
+         "k_reni_wide256<0, false>": "k_reni_wide256<0>",                                                  # (forward / statistics at H = 256; round 6: <MODE, FILM>)
          "k_dw_frag<256, false>": "k_dw_frag<256>",
          "k_reni_main<reni::PolF32, 128, 0, false>": "k_reni_main<f32,H=128,FWD>"}
 sha = kernel_src_sha()
