@@ -197,7 +197,11 @@ int reni_train_step_rows(const reni_plan* plan, int64_t B, int64_t P, float* Z_t
  * overlap != 0: the gradient of layers >= 2 + head (final before the ring kernel runs) is all-reduced on the library's own
  * communication stream beside the rest of the backward pass, the remainder (first layer, layer 1) behind it on the caller's stream --
  * two collectives on `comm`, issued in the same order on every rank; element for element the same sums.
- * With a one-rank communicator the results are bit-equal to reni_train_step_rows (tests/test_gpu_dist.py). */
+ * With a one-rank communicator the results are bit-equal to reni_train_step_rows (tests/test_gpu_dist.py).
+ * The skip decision of a staged step (see reni_train_step_rows) is all-reduced with MAX over `comm` in front of the gradient -- one
+ * more 4-byte collective per call, issued on every rank whether or not its own step was staged: a batch that is not the staged one on
+ * ANY rank skips the step on EVERY rank (the replicas stay replicas); on a skipped step the layer-1 slice of dparams, which this
+ * call's optimiser launch would have written, is NaN like the rest of the gradient. */
 int reni_train_step_rows_dp(const reni_plan* plan, int64_t B, int64_t P, float* Z_table, int64_t n_rows, const int64_t* idx,
                             const int64_t* idx_next, const float* D, int64_t d_batch_stride, float* params, const float* target,
                             const int64_t target_strides[3], const float* weight, const int64_t weight_strides[3],
