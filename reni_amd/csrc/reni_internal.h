@@ -98,8 +98,9 @@ hipError_t launch_train_film(int which, const MainArgs& a, int grid, hipStream_t
 hipError_t launch_dw1_film(const MainArgs& a, int grid, hipStream_t s);
 int train_film_lds_bytes(int which);
 // the H = 256 persistent chain (reni_tu_wide.hip): which = 0 forward / statistics, 1 frozen-decoder forward + loss + backward
-hipError_t launch_wide256(int which, const MainArgs& a, int grid, hipStream_t s);  // (2: the training form, with launch_wide_head_dw behind it; 3: FiLM forward)
+hipError_t launch_wide256(int which, const MainArgs& a, int grid, hipStream_t s);  // (2: the training form, with launch_wide_head_dw behind it; 3: FiLM forward / statistics; 4: FiLM training form)
 int wide256_film_max_layers();  // hidden FiLM layers whose per-image tables fit the forward instance's LDS region
+int wide256_film_train_max_layers();  // ... and the training form's (4: the default model's; its tables alias the dA exchange alone)
 hipError_t launch_wide_head_dw(const MainArgs& a, int grid, hipStream_t s);
 
 struct PrepArgs {

@@ -333,3 +333,47 @@ def test_film_forward_at_the_shipped_width_on_the_wide_kernel(dev, monkeypatch, 
     r_w = float((outs["wide"] - outs["f32"]).pow(2).mean().sqrt()); r_g = float((outs["generic"] - outs["f32"]).pow(2).mean().sqrt())
     assert e_w <= 5e-3 and e_w <= 1.5 * e_g + 2e-4 and r_w <= 1.2 * r_g + 2e-5, (e_w, e_g, r_w, r_g)
     assert float((outs["wide"] - outs["generic"]).abs().max()) <= 2.5e-3
+
+
+@pytest.mark.parametrize("fixed", [False, True])
+@pytest.mark.parametrize("B,W,nF", [(3, 64, 5), (5, 32, 3), (2, 32, 6)])
+def test_film_backward_at_the_shipped_width_on_the_wide_chain(dev, monkeypatch, B, W, nF, fixed):
+    """Round 6: every FiLM backward call at 256 features with up to four hidden FiLM layers -- the reference's default model
+    (configs/default.py:9,13), trainable or frozen decoder -- runs its chain on k_reni_wide256<2, FILM> in front of the fragment stream's
+    consumers (k_dw_frag<256, true>: weight gradients, d(freq), d(phase); k_wide_head_dw).  Loss, dZ and every parameter's gradient
+    (SIREN, head, mapping network) against the fp32 kernels (pinned to the reference by G11 and the oracle tests) and against the generic
+    bf16 chain (RENI_NO_PERSIST: other bits -- proof that the wide form ran -- and the same error class).  nF = 6 (five hidden layers:
+    the tables do not fit) stays on the generic chain: there the two runs must be bit-identical."""
+    from reni_amd.film import RENIAutoDecoderFiLM
+    from reni_amd.utils import get_directions, get_sineweight
+    D, S = get_directions(W).to(dev), get_sineweight(W).to(dev)
+    T = (torch.rand(B, D.shape[1], 3, generator=torch.Generator().manual_seed(11)) * 2 - 1).to(dev)
+    res = {}
+    for name, env, dtype in (("wide", None, "bf16"), ("generic", "1", "bf16"), ("f32", None, "f32")):
+        if env:
+            monkeypatch.setenv("RENI_NO_PERSIST", env)
+        else:
+            monkeypatch.delenv("RENI_NO_PERSIST", raising=False)
+        torch.manual_seed(3)
+        m = RENIAutoDecoderFiLM(B, 36, "SO2", 256, nF, 64, 2, 3, "tanh", fixed)
+        with torch.no_grad():
+            m.Z.normal_(generator=torch.Generator().manual_seed(4))
+            m.Z.mul_(0.5)
+        m.set_compute_dtype(dtype).to(dev)
+        Zd = m.Z.detach().clone().requires_grad_(True)
+        terms = m.fused_loss(Zd, D, T, S)
+        terms[0].backward()
+        res[name] = (float(terms[0]), Zd.grad.detach().cpu(), _grads(m))
+    monkeypatch.delenv("RENI_NO_PERSIST", raising=False)
+    lw, zw, gw = res["wide"]; lg, zg, gg = res["generic"]; lf, zf, gf = res["f32"]
+    if nF - 1 <= 4:
+        assert not torch.equal(zw, zg), "the wide chain did not run (bit-identical to RENI_NO_PERSIST)"
+    else:
+        assert torch.equal(zw, zg) and lw == lg
+    assert abs(lw - lf) <= 5e-3 * abs(lf) and torch.isfinite(zw).all()
+    e_w, e_g = O.rel_l2(zw.numpy(), zf.numpy()), O.rel_l2(zg.numpy(), zf.numpy())
+    assert e_w <= 3e-2 and e_w <= 1.5 * e_g + 2e-3, ("dZ", e_w, e_g)
+    assert bool(gw) == (not fixed)
+    for k, v in gf.items():
+        ew, eg = O.rel_l2(gw[k].numpy(), v.numpy()), O.rel_l2(gg[k].numpy(), v.numpy())
+        assert ew <= 5e-2 and ew <= 1.5 * eg + 5e-3, (k, ew, eg)
