@@ -215,6 +215,14 @@ def flop_train(nd, H, L):
     return 2 * (F + Bt)
 
 
+def flop_film(nd, H, L):
+    """--config film: SURVEY 8(d)'s formulas with L hidden FiLM layers behind the folded first one: F = (ND+2) H + 2 ND + L H^2 + 3 H,
+    Bt = 2 (L H^2 + 3 H) + (ND+2) H + ND H + 2 ND; 2 FLOP / MAC.  (ND=36, H=128, L=4: 424 480.)"""
+    F = (nd + 2) * H + 2 * nd + L * H * H + 3 * H
+    Bt = 2 * (L * H * H + 3 * H) + (nd + 2) * H + nd * H + 2 * nd
+    return 2 * (F + Bt)
+
+
 def flop_fwd(nd, H, L):
     """forward only: 2 x ((ND+2) H + 2 ND + L H^2 + 3 H)  (ND=49, H=128, L=5: 177 860)"""
     return 2 * ((nd + 2) * H + 2 * nd + L * H * H + 3 * H)
@@ -322,7 +330,7 @@ def run_config(cfg, args, rank, world, dev, batch=None, steps=None, warmup=None,
         from reni_amd.film import RENIAutoDecoderFiLM
         N_IMAGES, H_IMG, W_IMG, ND, B = 615, 128, 256, 36, batch or 64
         owned = rdist.owned_indices(N_IMAGES, rank, world)
-        model = RENIAutoDecoderFiLM(N_IMAGES, ND, "SO2", 128, 5, 128, 3, 3, "tanh", False)
+        model = RENIAutoDecoderFiLM(N_IMAGES, ND, "SO2", hidden, 5, hidden, 3, 3, "tanh", False)   # (hidden = 256: the reference's default model, configs/default.py:9-13)
     elif cfg == "c4":
         N_IMAGES, H_IMG, W_IMG, ND, B = 21, 128, 256, 36, batch or 21
         owned = list(range(N_IMAGES))  # every rank optimises its own 21 held-out maps (no shared state, no collective)
@@ -459,10 +467,12 @@ def _measure(shape, args, world, dev, dtype, step, barrier, steps, warmup, eng, 
         workload = (f"BASELINE config 2: 615-image set, {shape['res'][0]}x{shape['res'][1]} equirect, ND=36, 5x{H} SIREN, SO2, tanh, "
                     "AutoDecoder, RENITrainLoss; full training step (fwd+loss+bwd, grad all-reduce, Adam)")
     elif cfg == "film":
-        flop = FLOP_FILM
-        kernel = "k_reni_train_bf16<128,true,false,true>" if dtype == "bf16" else "k_reni_main<f32,H=128,FWD_BWD,FILM>"
-        workload = ("config 2's set and step with the reference's default conditioning: RENIAutoDecoderFiLM, SO2, ND=36, 5 FiLM "
-                    "layers x 128, mapping network 3 x 128, tanh; full training step (mapping network, fwd+loss+bwd, glue "
+        flop = flop_film(shape["ND"], H, 4)
+        assert H != 128 or flop == FLOP_FILM
+        kernel = (("k_reni_train_bf16<128,true,false,true>" if H == 128 else "k_reni_wide256<2,FILM>") if dtype == "bf16"
+                  else f"k_reni_main<f32,H={H},FWD_BWD,FILM>")
+        workload = (f"config 2's set and step with the reference's default conditioning: RENIAutoDecoderFiLM, SO2, ND=36, 5 FiLM "
+                    f"layers x {H}, mapping network 3 x {H}, tanh; full training step (mapping network, fwd+loss+bwd, glue "
                     "backward, grad all-reduce, Adam over decoder + mapping network + latents)")
     elif cfg == "c4":
         flop = flop_frozen(shape["ND"], H, 5)
@@ -576,6 +586,8 @@ def sub_record(name, args, rank, world, dev):
         m = run_config("c4", args, rank, world, dev, hidden=256, **kw)
     elif name == "c4_h256_dense":
         m = run_config("c4", args, rank, world, dev, hidden=256, dense=True, **kw)
+    elif name == "film_h256":  # the reference's DEFAULT model at its shipped width (configs/default.py:9,13): FiLM, 5 x 256, mapping 3 x 256
+        m = run_config("film", args, rank, world, dev, hidden=256, **kw)
     elif name == "fwd_h256":  # config 5's shape (4 x 524 288 directions, ND = 49) forward at H = 256 in bf16
         m = run_config("c5", args, rank, world, dev, hidden=256, force_dtype="bf16", **kw)
     else:
@@ -729,7 +741,7 @@ def main():
         # configurations whose ranks are independent (c4, c5: rank 0's own replica).
         also = {}
         user_dtype = args.dtype
-        names = (("c4", "c4_dense", "c4_pixels", "c4_f32", "c5", "film", "c2_b100") + tuple(f"c2_curric_{h}x{w}" for h, w in CURRIC) + ("c2_h256", "c4_h256", "c4_h256_dense", "fwd_h256")) if world == 1 else ("c4", "c5")
+        names = (("c4", "c4_dense", "c4_pixels", "c4_f32", "c5", "film", "c2_b100") + tuple(f"c2_curric_{h}x{w}" for h, w in CURRIC) + ("c2_h256", "c4_h256", "c4_h256_dense", "fwd_h256", "film_h256")) if world == 1 else ("c4", "c5")
         for c in names:
             args.dtype = None
             try:

@@ -361,7 +361,7 @@ def test_bench_contract_line_stays_short_and_last(capsys):
            "exchange": {"kind": "inside reni_train_step_rows_dp (librccl, the library's communicator)", "avg_us_on_compute_stream": 41.51234,
                         "comm_fallback": "x" * 200}}
     names = ("c4", "c4_dense", "c4_pixels", "c4_f32", "c5", "film", "c2_b100", "c2_curric_16x32", "c2_curric_32x64", "c2_curric_64x128", "c2_h256",
-             "c4_h256", "c4_h256_dense", "fwd_h256")
+             "c4_h256", "c4_h256_dense", "fwd_h256", "film_h256")
     also = {n: {"value": 1234567890.1234, "ms_per_step": 0.4645531234, "roofline": dict(roof), "workload": "w" * 300, "paths": paths} for n in names}
     also["film"] = {"error": "RuntimeError: " + "e" * 300}
     sustained = {"value": 1351431234.5, "ms_per_step": 1.55181234, "kernel_avg_ms": 1.301341234, "frac": 0.3369941234, "frac_step": 0.281234, "steps": 20,

@@ -228,7 +228,7 @@ def test_bench_default_line_carries_every_baseline_config_and_the_capi_exchange(
     step on a one-rank communicator (the same call path as N > 1)."""
     line, also = _run_bench({}, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", with_also=True)
     curric = {"c2_curric_16x32", "c2_curric_32x64", "c2_curric_64x128"}   # configs/experiment.yaml:29-34, B = 100
-    assert set(also) == {"c4", "c4_dense", "c4_pixels", "c4_f32", "c5", "film", "c2_b100", "c2_h256", "c4_h256", "c4_h256_dense", "fwd_h256"} | curric, {k: v.get("error") for k, v in also.items()}
+    assert set(also) == {"c4", "c4_dense", "c4_pixels", "c4_f32", "c5", "film", "c2_b100", "c2_h256", "c4_h256", "c4_h256_dense", "fwd_h256", "film_h256"} | curric, {k: v.get("error") for k, v in also.items()}
     assert all("error" not in v for v in also.values()), {k: v.get("error") for k, v in also.items()}
     assert set(line["also"]) == set(also)
     for k, v in also.items():   # the contract line's triple is the sub-record's (to the printed digits)
@@ -246,7 +246,7 @@ def test_bench_default_line_carries_every_baseline_config_and_the_capi_exchange(
     px = also["c4_pixels"]["weight_sparsity"]
     assert px["flag"] == "RENI_WEIGHT_COMPACT" and abs(px["tiles_visited"] - 49 / 256) < 1e-6
     assert also["c4_pixels"]["roofline"]["kernel_avg_ms"] < 0.8 * also["c4"]["roofline"]["kernel_avg_ms"]
-    for c, flop in (("c4", 348448), ("c4_dense", 348448), ("c4_pixels", 348448), ("c5", 177860), ("film", 424480), ("c2_h256", 2028320)):
+    for c, flop in (("c4", 348448), ("c4_dense", 348448), ("c4_pixels", 348448), ("c5", 177860), ("film", 424480), ("c2_h256", 2028320), ("film_h256", 1635104)):
         r = also[c]
         assert r["value"] > 0 and r["ms_per_step"] > 0 and r["roofline"]["flop_per_sample"] == flop and r["roofline"]["kernel_avg_ms"] > 0
         assert 0 < r["roofline"]["frac_step"] <= r["roofline"]["frac"] * 1.0001 and r["ms_per_step_mean"] >= r["ms_per_step"]
