@@ -282,3 +282,26 @@ def test_wide_stream_path_more_tiles_than_workgroups(dev):
     a = plan.forward_loss_backward(Z.to(dev), D.to(dev), fp, T.to(dev), W.to(dev))
     b = plan.forward_loss_backward(Z.to(dev), D.to(dev), fp, T.to(dev), W.to(dev))
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [dict(H=128, L=3, w0=20.0, wh=45.0), dict(H=128, L=4, w0=45.0, wh=12.0), dict(H=128, L=5, w0=7.5, wh=30.0),
+                                 dict(H=256, L=3, w0=20.0, wh=45.0), dict(H=64, L=2, w0=12.0, wh=40.0)],
+                         ids=lambda c: f"H{c['H']}-L{c['L']}-w{c['w0']:g}-{c['wh']:g}")
+def test_unequal_omegas_vs_oracle(dev, dtype, cfg):
+    """FIRST_OMEGA_0 != HIDDEN_OMEGA_0 (the reference's config keys, RENI.py:128-178; every shipped config sets both to 30, and so did every
+    test until round 6).  On the persistent bf16 kernels the omegas enter through the packed images' scales, the constant on d loss / d y
+    and the per-layer constants of the weight gradients (c_l = (omega_hidden / omega_first) (8 / 2 pi)^l): a
+    training call (every parameter's gradient) and a frozen-decoder call (dZ), with the cosine term, against the fp64 oracle."""
+    spec = O.DecoderSpec(9, "SO2", cfg["H"], cfg["L"], 3, True, "tanh", cfg["w0"], cfg["wh"])
+    params, Z, D, W, T = random_problem(spec, 3, 0, seed=61, grid_w=64)
+    plan = make_plan(spec, dtype)
+    _check(plan, spec, params, Z, D, W, T, dev, dtype)
+    B, P = 3, D.shape[1]
+    ref = O.fwd_loss_bwd(spec, params, Z, D.expand(B, P, 3), T, W.expand(B, P, 3), "test", 1e-3, 1e-1, need_dw=False)
+    lt, dZ, dp, _ = plan.forward_loss_backward(Z.to(dev), D.to(dev), flat_params(spec, params).to(dev), T.to(dev), W.to(dev), loss_kind="test",
+                                               alpha=1e-3, beta=1e-1, need_dw=False)
+    assert dp is None
+    tol = TOL[dtype]
+    assert abs(float(lt[0]) - ref["loss_terms"][0]) <= tol["loss"] * abs(ref["loss_terms"][0])
+    assert O.rel_l2(dZ.cpu().numpy(), ref["dZ"].numpy()) <= tol["grad"]
