@@ -351,3 +351,49 @@ def test_film_latent_trajectory_g16(dtype):
         assert rel.max() <= 1e-3 and cz >= 0.999, (rel.max(), cz)       # (measured 1.6e-4, 0.9995)
     else:
         assert rel.max() <= max(1.5 * rel_ac.max(), 2e-2) and cz >= cz_ac - 0.05, (rel.max(), rel_ac.max(), cz, cz_ac)
+
+
+# ---- G17: decoder training with the DEFAULT conditioning at the rate the reference trains it at (configs/default.py:9, :25) ------------
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_film_training_trajectory_g17(dtype):
+    """FIT_DECODER with FiLM (RENI_module.py:80-146 on RENIAutoDecoderFiLM): 100 Adam(1e-5) steps over net + final_layer + mapping_network
+    + latents through TrainEngine (reni_film_model_forward_loss_backward + the fused Adam over the flat buffer) against the reference's
+    fp32 run and its own code under autocast(bfloat16) (tests/golden/make_g17_film_training.py).  Weights and latents come from the seed.
+    At this rate the run is stable (the loss falls 0.63 -> 0.26; autocast stays within 0.13 % of fp32 everywhere), so the bands are
+    tight: fp32 kernels 2e-4 (three steps 2e-5), bf16 kernels 3 x the reference's own autocast deviation."""
+    from reni_amd.engine import TrainEngine
+    from reni_amd.film import RENIAutoDecoderFiLM
+    from reni_amd.utils import get_directions, get_sineweight
+    dev = torch.device("cuda:0")
+    g, f = load_golden("g15_c2_trajectory.npz"), load_golden("g17_film_c2_trajectory.npz")
+    N, B, W = g["imgs"].shape[0], int(g["B"]), int(g["W"])
+    torch.manual_seed(int(f["seed"]))
+    m = RENIAutoDecoderFiLM(N, 36, "SO2", 128, 5, 128, 3, 3, "tanh", False)
+    assert abs(float(m.Z.detach().double().abs().sum()) - float(f["Z0_abs_sum"])) <= 1e-3   # the same draw as the reference's
+    m.set_compute_dtype(dtype).to(dev)
+    D, S = get_directions(W).to(dev), get_sineweight(W).to(dev)
+    imgs = torch.from_numpy(g["imgs"]).to(dev)
+    P = D.shape[1]
+    eng = TrainEngine(m, lr=float(f["lr"]))
+    losses = []
+    for it in range(int(f["steps"])):
+        idx = torch.arange(B, device=dev) + (it % (N // B)) * B
+        t = eng.step(idx, imgs[idx].permute(0, 2, 3, 1).view(B, P, 3), S, D)
+        losses.append(float(t[0]))
+    losses = np.array(losses)
+    ref, ac = f["losses"], f["losses_autocast_bf16"]
+    rel, rel_ac = np.abs(losses - ref) / ref, np.abs(ac - ref) / ref
+    Zf = m.Z.detach().cpu().numpy()
+    dz, dz_ac = np.abs(Zf - f["Z_final"]).max(), np.abs(f["Z_final_autocast_bf16"] - f["Z_final"]).max()
+    print(f"G17 FiLM training {dtype}: max rel loss deviation {rel.max():.3e} (first three {rel[:3].max():.3e}; the reference under autocast "
+          f"{rel_ac.max():.3e}); final latents max |dZ| {dz:.3e} (autocast {dz_ac:.3e})")
+    if dtype == "f32":
+        assert rel[:3].max() <= 2e-5 and rel.max() <= 2e-4, rel
+        assert dz <= 1e-4, dz                      # 100 steps of 1e-5 move a latent by at most 1e-3
+    else:
+        assert rel.max() <= 3.0 * rel_ac.max(), (rel.max(), rel_ac.max())
+        assert dz <= max(3.0 * dz_ac, 2e-4), (dz, dz_ac)
+    for k, p in m.named_parameters():
+        if k != "Z":
+            ref_n = float(f["fn." + k])
+            assert abs(float(p.detach().double().norm()) - ref_n) <= 2e-3 * ref_n, k
