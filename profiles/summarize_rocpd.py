@@ -21,12 +21,13 @@ def main():
     if len(sys.argv) > 3:
         k = int(sys.argv[3])
         w = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-        key = "k_reni_train_bf16<128, true, false, false, true>"
-        allr = [r[0] for r in c.execute(f"select end-start from kernels where {name_col} like '%{key}%' order by start").fetchall()]
-        for title, d in (("headline window (launches %d..%d)" % (w, w + k - 1), allr[w:w + k]), ("sustained window (the last %d launches)" % k, allr[-k:])):
-            if d:
-                out.append("")
-                out.append(f"{title} of `{key}`: avg {sum(d)/len(d)/1e3:.1f} us, min {min(d)/1e3:.1f} us, max {max(d)/1e3:.1f} us")
+        # (prefixes: the training instance has a sixth template argument since round 5 -- L0X -- and the exact round-4 name matched nothing)
+        for key in ("k_reni_train_bf16<128, true, false, false, true", "k_reni_l0_ring<128>", "k_reni_dw1_ring<128"):
+            allr = [r[0] for r in c.execute(f"select end-start from kernels where {name_col} like '%{key}%' order by start").fetchall()]
+            for title, d in (("headline window (launches %d..%d)" % (w, w + k - 1), allr[w:w + k]), ("sustained window (the last %d launches)" % k, allr[-k:])):
+                if d:
+                    out.append("")
+                    out.append(f"{title} of `{key}...`: avg {sum(d)/len(d)/1e3:.1f} us, min {min(d)/1e3:.1f} us, max {max(d)/1e3:.1f} us")
     text = "\n".join(out)
     print(text)
     if len(sys.argv) > 2:

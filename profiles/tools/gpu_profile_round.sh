@@ -44,7 +44,8 @@ for c in c2 c4 c5 film c2_h256; do
   # c2: the DEFAULT command as the driver runs it (the headline's 5 + 20 steps first, the sub-records, the same steps again): the
   # summary's last two lines are the averages of the headline's and of the sustained window's 20 timed launches
   X="--config $c --steps 10 --warmup 2 --no-also"; K=""; [ $c = c2 ] && { X="--steps 20 --warmup 5"; K="20 5"; }
-  rocprofv3 --kernel-trace --stats -d $O/kt_$c -o k -- python3 bench.py $X --no-cpu-baseline > $O/kt_$c.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/kt_$c -o k -- python3 bench.py $X --no-cpu-baseline > $O/kt_$c.txt 2> $O/kt_$c.log
+  [ $c = c2 ] && tail -n 1 $O/kt_$c.txt > $O/bench_c2_profiled.json   # (the line of the PROFILED process: its kernel_avg_ms is what the summary's headline window must agree with)
   python3 profiles/summarize_rocpd.py $O/kt_$c/k_results.db $O/kernel_stats_$c.md $K > /dev/null 2>&1 || ls -R $O/kt_$c | head
   { [ $c = c2 ] || [ $c = film ] || [ $c = c2_h256 ]; } && python3 profiles/timeline_rocpd.py $O/kt_$c/k_results.db > $O/step_timeline_$c.txt 2>/dev/null
   rm -rf $O/kt_$c

@@ -360,7 +360,8 @@ def test_film_training_trajectory_g17(dtype):
     + latents through TrainEngine (reni_film_model_forward_loss_backward + the fused Adam over the flat buffer) against the reference's
     fp32 run and its own code under autocast(bfloat16) (tests/golden/make_g17_film_training.py).  Weights and latents come from the seed.
     At this rate the run is stable (the loss falls 0.63 -> 0.26; autocast stays within 0.13 % of fp32 everywhere), so the bands are
-    tight: fp32 kernels 2e-4 (three steps 2e-5), bf16 kernels 3 x the reference's own autocast deviation."""
+    tight: fp32 kernels 1e-5 (measured 2.3e-7 over all 100 steps, latents within 2.4e-7), bf16 kernels NO WORSE than the reference's
+    own autocast run (measured 2.4e-4 against 1.3e-3; latents 3.6e-5 against 3.3e-4)."""
     from reni_amd.engine import TrainEngine
     from reni_amd.film import RENIAutoDecoderFiLM
     from reni_amd.utils import get_directions, get_sineweight
@@ -388,11 +389,11 @@ def test_film_training_trajectory_g17(dtype):
     print(f"G17 FiLM training {dtype}: max rel loss deviation {rel.max():.3e} (first three {rel[:3].max():.3e}; the reference under autocast "
           f"{rel_ac.max():.3e}); final latents max |dZ| {dz:.3e} (autocast {dz_ac:.3e})")
     if dtype == "f32":
-        assert rel[:3].max() <= 2e-5 and rel.max() <= 2e-4, rel
-        assert dz <= 1e-4, dz                      # 100 steps of 1e-5 move a latent by at most 1e-3
+        assert rel[:3].max() <= 2e-6 and rel.max() <= 1e-5, rel
+        assert dz <= 5e-6, dz                      # 100 steps of 1e-5 move a latent by at most 1e-3
     else:
-        assert rel.max() <= 3.0 * rel_ac.max(), (rel.max(), rel_ac.max())
-        assert dz <= max(3.0 * dz_ac, 2e-4), (dz, dz_ac)
+        assert rel.max() <= rel_ac.max(), (rel.max(), rel_ac.max())
+        assert dz <= dz_ac, (dz, dz_ac)
     for k, p in m.named_parameters():
         if k != "Z":
             ref_n = float(f["fn." + k])
