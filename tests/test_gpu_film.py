@@ -303,7 +303,7 @@ def test_film_train_engine_step_equals_autograd_plus_adam(dev):
         assert float((sa[k] - sb[k]).abs().max()) <= 2e-6 + 1e-4 * float(sb[k].abs().max()) * 1e-2, k
 
 
-@pytest.mark.parametrize("B,W,nF", [(4, 256, 5), (3, 64, 5), (5, 32, 3), (2, 128, 6)])
+@pytest.mark.parametrize("B,W,nF", [(4, 256, 5), (3, 64, 5), (5, 32, 3), (2, 128, 6), (3, 16, 5)])
 def test_film_forward_at_the_shipped_width_on_the_wide_kernel(dev, monkeypatch, B, W, nF):
     """Round 6 (second half): the forward pass of the reference's DEFAULT model at its shipped width -- FiLM, 256
     features (configs/default.py:9,13; RENI.py:508-519, 565-586) -- runs on k_reni_wide256<0, FILM>: per-image (freq, phase) tables in
@@ -336,14 +336,16 @@ def test_film_forward_at_the_shipped_width_on_the_wide_kernel(dev, monkeypatch, 
 
 
 @pytest.mark.parametrize("fixed", [False, True])
-@pytest.mark.parametrize("B,W,nF", [(3, 64, 5), (5, 32, 3), (2, 32, 6)])
+@pytest.mark.parametrize("B,W,nF", [(3, 64, 5), (5, 32, 3), (2, 32, 6), (3, 16, 4), (5, 16, 5)])
 def test_film_backward_at_the_shipped_width_on_the_wide_chain(dev, monkeypatch, B, W, nF, fixed):
     """Round 6: every FiLM backward call at 256 features with up to four hidden FiLM layers -- the reference's default model
     (configs/default.py:9,13), trainable or frozen decoder -- runs its chain on k_reni_wide256<2, FILM> in front of the fragment stream's
     consumers (k_dw_frag<256, true>: weight gradients, d(freq), d(phase); k_wide_head_dw).  Loss, dZ and every parameter's gradient
     (SIREN, head, mapping network) against the fp32 kernels (pinned to the reference by G11 and the oracle tests) and against the generic
     bf16 chain (RENI_NO_PERSIST: other bits -- proof that the wide form ran -- and the same error class).  nF = 6 (five hidden layers:
-    the tables do not fit) stays on the generic chain: there the two runs must be bit-identical."""
+    the tables do not fit) stays on the generic chain: there the two runs must be bit-identical.  W = 16: one 128-sample tile per image
+    and an ODD number of tiles -- the last pair's second group has no tile of its own (its unconditional stream stores must carry its
+    neighbour's words: the first version of the instance wrote zeros over them, found by tests/test_gpu_fuzz.py at 600 cases)."""
     from reni_amd.film import RENIAutoDecoderFiLM
     from reni_amd.utils import get_directions, get_sineweight
     D, S = get_directions(W).to(dev), get_sineweight(W).to(dev)
