@@ -6,7 +6,8 @@ import torch
 from oracle import reni_oracle as O
 from tests.util import random_problem, make_plan, flat_params
 dev = torch.device("cuda:0")
-spec = O.DecoderSpec(36, "SO2", 128, 5, 3, True, "tanh")
+HID = int(sys.argv[3]) if len(sys.argv) > 3 else 128   # (256: the sparse / compact walks of k_reni_wide256<1>)
+spec = O.DecoderSpec(36, "SO2", HID, 5, 3, True, "tanh")
 plan = make_plan(spec, "bf16")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 g = torch.Generator().manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -52,4 +53,4 @@ for it in range(N):
     if msg:
         bad += 1
         print("iter", it, "B", B, "grid", gw, msg, flush=True)
-print("iterations", N, "bad", bad, "seconds", round(time.time() - t0, 1))
+print("hidden", HID, "iterations", N, "bad", bad, "seconds", round(time.time() - t0, 1))
