@@ -20,13 +20,17 @@ sys.path.insert(0, HERE)
 import make_golden as mg  # noqa: E402
 
 SEED = 7
+# python make_g16_film_trajectory.py 256 -> G18: the same loop on the reference's SHIPPED default model (configs/default.py:13-16:
+# 256 features, 5 FiLM layers, mapping network 3 x 256) -> g18_film256_c4_trajectory.npz
+WIDTH = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+OUT = "g16_film_c4_trajectory.npz" if WIDTH == 128 else f"g18_film{WIDTH}_c4_trajectory.npz"
 
 
 def main():
     g = np.load(os.path.join(HERE, "g14_c4_trajectory.npz"))
     N, W = 3, int(g["W"])
     torch.manual_seed(SEED)
-    m = mg.ref.RENIAutoDecoderFiLM(N, 36, "SO2", 128, 5, 128, 3, 3, "tanh", True)
+    m = mg.ref.RENIAutoDecoderFiLM(N, 36, "SO2", WIDTH, 5, WIDTH, 3, 3, "tanh", True)
     assert float(m.Z.abs().sum()) == 0.0
     imgs = torch.from_numpy(g["imgs"]); mask = torch.from_numpy(g["mask"])
     D1 = mg.ref_utils.get_directions(W); S1 = mg.ref_utils.get_sineweight(W) * mask
@@ -58,10 +62,10 @@ def main():
 
     rec_at, terms, Zf, img = run(False)
     _, terms_ac, Zf_ac, img_ac = run(True)
-    np.savez_compressed(os.path.join(HERE, "g16_film_c4_trajectory.npz"), seed=np.int64(SEED), rec_at=np.array(rec_at), terms=terms,
+    np.savez_compressed(os.path.join(HERE, OUT), seed=np.int64(SEED), width=np.int64(WIDTH), rec_at=np.array(rec_at), terms=terms,
                         terms_autocast_bf16=terms_ac, Z_after_200=Zf, Z_after_200_autocast_bf16=Zf_ac, img_after_200=img.astype(np.float32),
                         img_after_200_autocast_bf16=img_ac.astype(np.float16), steps=np.int64(steps), lr=np.float64(1e-1))
-    print("saved", os.path.getsize(os.path.join(HERE, "g16_film_c4_trajectory.npz")) / 1024, "KiB")
+    print("saved", OUT, os.path.getsize(os.path.join(HERE, OUT)) / 1024, "KiB")
 
 
 if __name__ == "__main__":
