@@ -22,6 +22,10 @@ import make_golden as mg  # noqa: E402
 
 SEED = 7
 LR = float(os.environ.get("G17_LR", "1e-5"))   # configs/default.py:25: RENI.FIT_DECODER.LR_START
+# python make_g17_film_training.py 256 -> G19: the same loop on the reference's SHIPPED default model (configs/default.py:13-20: 256 features,
+# mapping network 3 x 256) -> g19_film256_c2_trajectory.npz
+WIDTH = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+OUT = "g17_film_c2_trajectory.npz" if WIDTH == 128 else f"g19_film{WIDTH}_c2_trajectory.npz"
 
 
 def main():
@@ -34,7 +38,7 @@ def main():
 
     def run(autocast):
         torch.manual_seed(SEED)
-        m = mg.ref.RENIAutoDecoderFiLM(N, 36, "SO2", 128, 5, 128, 3, 3, "tanh", False)
+        m = mg.ref.RENIAutoDecoderFiLM(N, 36, "SO2", WIDTH, 5, WIDTH, 3, 3, "tanh", False)
         Z0 = m.Z.detach().numpy().copy()
         opt = torch.optim.Adam(m.parameters(), lr=LR)
         losses = []
@@ -61,7 +65,7 @@ def main():
         v = p.detach().numpy()
         arrs["fn." + k] = np.float64(np.linalg.norm(v.astype(np.float64)))
         arrs["fh." + k] = v.reshape(-1)[:32].copy()
-    np.savez_compressed(os.path.join(HERE, "g17_film_c2_trajectory.npz"), seed=np.int64(SEED), Z0_abs_sum=np.float64(np.abs(Z0).sum()),
+    np.savez_compressed(os.path.join(HERE, OUT), seed=np.int64(SEED), width=np.int64(WIDTH), Z0_abs_sum=np.float64(np.abs(Z0).sum()),
                         losses=losses, losses_autocast_bf16=losses_ac, Z_final=m.Z.detach().numpy(),
                         Z_final_autocast_bf16=m_ac.Z.detach().numpy(), steps=np.int64(steps), lr=np.float64(LR), **arrs)
     dev = np.abs(losses_ac - losses) / losses

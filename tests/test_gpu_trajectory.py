@@ -368,8 +368,9 @@ def test_film_latent_trajectory_shipped_width_g18(dtype):
 
 
 # ---- G17: decoder training with the DEFAULT conditioning at the rate the reference trains it at (configs/default.py:9, :25) ------------
+@pytest.mark.parametrize("fixture", ["g17_film_c2_trajectory.npz", "g19_film256_c2_trajectory.npz"], ids=["g17", "g19_shipped_width"])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_film_training_trajectory_g17(dtype):
+def test_film_training_trajectory_g17(dtype, fixture):
     """FIT_DECODER with FiLM (RENI_module.py:80-146 on RENIAutoDecoderFiLM): 100 Adam(1e-5) steps over net + final_layer + mapping_network
     + latents through TrainEngine (reni_film_model_forward_loss_backward + the fused Adam over the flat buffer) against the reference's
     fp32 run and its own code under autocast(bfloat16) (tests/golden/make_g17_film_training.py).  Weights and latents come from the seed.
@@ -380,10 +381,11 @@ def test_film_training_trajectory_g17(dtype):
     from reni_amd.film import RENIAutoDecoderFiLM
     from reni_amd.utils import get_directions, get_sineweight
     dev = torch.device("cuda:0")
-    g, f = load_golden("g15_c2_trajectory.npz"), load_golden("g17_film_c2_trajectory.npz")
+    g, f = load_golden("g15_c2_trajectory.npz"), load_golden(fixture)
     N, B, W = g["imgs"].shape[0], int(g["B"]), int(g["W"])
+    width = int(f["width"]) if "width" in f else 128   # (G19: the shipped default model, 256 features -- k_reni_wide256<2, FILM> + k_dw_frag<256, true>)
     torch.manual_seed(int(f["seed"]))
-    m = RENIAutoDecoderFiLM(N, 36, "SO2", 128, 5, 128, 3, 3, "tanh", False)
+    m = RENIAutoDecoderFiLM(N, 36, "SO2", width, 5, width, 3, 3, "tanh", False)
     assert abs(float(m.Z.detach().double().abs().sum()) - float(f["Z0_abs_sum"])) <= 1e-3   # the same draw as the reference's
     m.set_compute_dtype(dtype).to(dev)
     D, S = get_directions(W).to(dev), get_sineweight(W).to(dev)
@@ -400,7 +402,7 @@ def test_film_training_trajectory_g17(dtype):
     rel, rel_ac = np.abs(losses - ref) / ref, np.abs(ac - ref) / ref
     Zf = m.Z.detach().cpu().numpy()
     dz, dz_ac = np.abs(Zf - f["Z_final"]).max(), np.abs(f["Z_final_autocast_bf16"] - f["Z_final"]).max()
-    print(f"G17 FiLM training {dtype}: max rel loss deviation {rel.max():.3e} (first three {rel[:3].max():.3e}; the reference under autocast "
+    print(f"{fixture[:3].upper()} FiLM training (width {width}) {dtype}: max rel loss deviation {rel.max():.3e} (first three {rel[:3].max():.3e}; the reference under autocast "
           f"{rel_ac.max():.3e}); final latents max |dZ| {dz:.3e} (autocast {dz_ac:.3e})")
     if dtype == "f32":
         assert rel[:3].max() <= 2e-6 and rel.max() <= 1e-5, rel
