@@ -20,6 +20,8 @@ steps.  The loss the loop is run for stays within 0.75 % of the reference's curv
 (Round 6: with the frozen-decoder calls' W^T images made exact multiples of the forward images the bf16 kernels end at cosine 0.76 and
 their completed maps at 48.9 / 47.6 dB -- ahead of the autocast run on both counts; FINDING 2 in test_c4_latent_trajectory_bf16_g14.)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -304,7 +306,15 @@ def _run_g16(dtype, dev, fixture="g16_film_c4_trajectory.npz"):
     N, W = g["imgs"].shape[0], int(g["W"])
     width = int(f["width"]) if "width" in f else 128
     torch.manual_seed(int(f["seed"]))
-    m = RENIAutoDecoderFiLM(N, 36, "SO2", width, 5, width, 3, 3, "tanh", True)
+    if "kind" in f and str(f["kind"]) == "concat":   # (G20: the concat decoder at 256 features, weights from the seed)
+        from reni_amd.models import RENIAutoDecoder
+        m = RENIAutoDecoder(N, 36, "SO2", width, 5, 3, True, "tanh", 30.0, 30.0, True)
+        if width == 128:   # (G21: G14's decoder -- the seed-42 config-2 weights g4_c2shape.npz carries)
+            m.load_state_dict({"model." + k: v for k, v in _decoder_sd().items()})
+        w_norm = float(sum(p.detach().double().pow(2).sum() for p in m.net.parameters()).sqrt())
+        assert abs(w_norm - float(f["w_norm"])) <= 1e-9 * w_norm, "the class does not draw the reference's weights from this seed"
+    else:
+        m = RENIAutoDecoderFiLM(N, 36, "SO2", width, 5, width, 3, 3, "tanh", True)
     assert float(m.Z.detach().abs().sum()) == 0.0
     m.set_compute_dtype(dtype).to(dev)
     D = get_directions(W).to(dev)
@@ -335,7 +345,10 @@ def test_film_latent_trajectory_g16(dtype):
     _check_film_trajectory(dtype, "g16_film_c4_trajectory.npz", "G16 FiLM", 48.0, 1e-3, 0.999)
 
 
-def _check_film_trajectory(dtype, fixture, tag, f32_psnr, f32_rel, f32_cos):
+def _check_film_trajectory(dtype, fixture, tag, f32_psnr, f32_rel, f32_cos, emu_psnr=None, emu_cos=None):
+    """emu_psnr / emu_cos (fixtures that carry `*_emulated_*`): the bf16 bars are taken against the reference's fp32-autograd run ON THE
+    NETWORK THE KERNEL EVALUATES (hidden weights bf16(W omega / 2 pi) 2 pi / omega for the persistent kernels, bf16(W) for the generic
+    ones -- RENI_NO_PERSIST -- head bf16(W_out), sine outputs rounded to bf16), not against the reference under autocast: FINDING 3 below."""
     dev = torch.device("cuda:0")
     g, f, terms, Z, img = _run_g16(dtype, dev, fixture)
     ref = f["terms"]
@@ -350,12 +363,25 @@ def _check_film_trajectory(dtype, fixture, tag, f32_psnr, f32_rel, f32_cos):
         print(f"{tag} {dtype}: final image PSNR vs the reference's fp32 image, {name} pixels: HIP {p_hip:.2f} dB, reference under autocast {p_ac:.2f} dB")
         if dtype == "f32":
             assert p_hip >= f32_psnr, (name, p_hip)          # (G16 measured 52.4 / 53.1 dB)
-        else:
+        elif emu_psnr is None:
             assert p_hip >= p_ac - 1.0, (name, p_hip, p_ac)  # (G16 measured 36.7 / 39.1 against 34.8 / 37.3)
+        else:
+            own = "generic" if os.environ.get("RENI_NO_PERSIST") else "persistent"
+            e_img = f[f"img_after_200_emulated_{own}"].astype(np.float32)
+            p_own, p_emu_ref = _psnr(img, e_img, sel), _psnr(e_img, ref_img, sel)
+            print(f"{tag} {dtype}: {name} pixels against the fp32-autograd run on the {own} network: {p_own:.2f} dB (that run against the fp32 network's: {p_emu_ref:.2f} dB)")
+            assert p_own >= emu_psnr and p_hip >= p_emu_ref - 1.5, (name, p_own, p_hip, p_emu_ref)
     if dtype == "f32":
         assert rel.max() <= f32_rel and cz >= f32_cos, (rel.max(), cz)       # (G16 measured 1.6e-4, 0.9995)
-    else:
+    elif emu_psnr is None:
         assert rel.max() <= max(1.5 * rel_ac.max(), 2e-2) and cz >= cz_ac - 0.05, (rel.max(), rel_ac.max(), cz, cz_ac)
+    else:
+        own = "generic" if os.environ.get("RENI_NO_PERSIST") else "persistent"
+        t_e = f[f"terms_emulated_{own}"]
+        rel_e = np.abs(terms[:, 0] - t_e[:, 0]) / t_e[:, 0]
+        cz_e = _cos(Z, f[f"Z_after_200_emulated_{own}"])
+        print(f"{tag} {dtype}: against the run on the {own} network: max rel loss deviation {rel_e.max():.3e}, final-latent cos {cz_e:.4f}")
+        assert rel_e.max() <= 5e-3 and cz_e >= emu_cos, (rel_e.max(), cz_e)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -365,6 +391,32 @@ def test_film_latent_trajectory_shipped_width_g18(dtype):
     network's backward -> dZ), fp32 on the generic kernels.  Same bars as G16: fp32 close to the reference's fp32 run, bf16 no worse than
     the reference's own code under autocast(bfloat16) less 1 dB (tests/golden/make_g16_film_trajectory.py 256)."""
     _check_film_trajectory(dtype, "g18_film256_c4_trajectory.npz", "G18 FiLM-256", 55.0, 5e-4, 0.999)   # (measured 60.0 / 61.1 dB, 8.9e-5, 0.9995; bf16 38.7 / 41.3 dB against autocast's 35.3 / 38.3)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_concat_latent_trajectory_shipped_width_g20(dtype):
+    """G14's loop on the concat decoder at 256 features (tests/golden/make_g20_concat256_trajectory.py): bf16 runs k_reni_wide256<1>
+    (frozen chain, forward / backward consistent weight images since round 6).  The loop that exposed the H = 128 kernels' inconsistent
+    images (FINDING 2) had no counterpart at this width.
+
+    FINDING 3 (round 6, profiles/r06_trajectory.md section 8): here the shipped kernel ends 46.5 dB from the reference's fp32 maps, the
+    generic bf16 kernel 50.6 dB and the reference under autocast 50.3 dB -- reproducibly over the perturbation ensemble -- and it is NOT a
+    kernel error: each kernel's dZ is the exact gradient of the network its forward pass evaluates to 1.4e-4 (fp64 autograd emulation,
+    the same for both kernels, along the whole path), and the reference's own fp32-autograd loop ON THOSE NETWORKS lands at 46.2 dB
+    (hidden weights bf16(W omega / 2 pi): the persistent kernels' images) and 50.4 dB (bf16(W)).  Which 2^-9 perturbation of the weights
+    the loop runs on decides where it ends: over arbitrary scales in front of the rounding 41.9 .. 52.9 dB.  "No worse than the
+    reference under autocast" is therefore a lottery, and the bf16 bars of this fixture are: (a) the kernel follows the fp32-autograd
+    run on ITS network (measured 54.0 / 55.9 dB on the unperturbed targets -- the ensemble's worst draw; 63 .. 75 dB on the six perturbed
+    ones; latent cos 0.989), and (b) it ends no further from the fp32 network's maps than that run does, less 1.5 dB."""
+    _check_film_trajectory(dtype, "g20_concat256_c4_trajectory.npz", "G20 concat-256", 80.0, 1e-4, 0.9999, emu_psnr=50.0, emu_cos=0.97)   # (fp32 kernels measured: 117 dB, 8.7e-7, 1.0000)
+
+
+def test_concat_latent_trajectory_on_its_own_network_g21():
+    """The same bars for G14's decoder (5 x 128: the frozen instance of k_reni_train_bf16, BASELINE config 4's kernel): G21 = G14's runs
+    again (bit-identical to g14_c4_trajectory.npz) plus the fp32-autograd runs on the two rounded networks
+    (tests/golden/make_g20_concat256_trajectory.py 128).  Measured: 56.4 / 58.4 dB, latent cos 0.944 against the run on the persistent
+    kernels' network (which itself ends 46.4 / 46.0 dB from the fp32 network's maps; the kernel 48.4 / 47.1)."""
+    _check_film_trajectory("bf16", "g21_concat128_c4_trajectory.npz", "G21 concat-128", 0, 0, 0, emu_psnr=50.0, emu_cos=0.9)
 
 
 # ---- G17: decoder training with the DEFAULT conditioning at the rate the reference trains it at (configs/default.py:9, :25) ------------
