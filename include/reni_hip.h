@@ -421,7 +421,8 @@ int reni_launch_info(const reni_plan* plan, int64_t B, int64_t P, int32_t* info4
  *           side stream 0/1, images per chunk of the H = 256 training path (= B: one pass), operand stream 0/1,
  *           fragment stream 0 / 1 bf16 / 2 fp32, environment overrides in force (bit 0 RENI_NO_PERSIST, 1 RENI_NO_SIDE_STREAM,
  *           2 RENI_FRAG_WS_CAP_MB, 3 RENI_DW1_OLD; 0 in a clean environment), workgroups }.
- * The selectors are read from the environment ONCE, at reni_plan_create; every alternative is a tested, correct path, and
+ * The selectors are read from the environment ONCE, at reni_plan_create (a switch is on when its variable is set to anything but ""
+ * or "0"); every alternative is a tested, correct path, and
  * bench.py prints this record so that a stray variable cannot silently change what is measured. */
 int reni_path_info(const reni_plan* plan, int64_t B, int64_t P, uint32_t flags, int32_t* info8);
 

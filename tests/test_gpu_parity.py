@@ -305,3 +305,19 @@ def test_unequal_omegas_vs_oracle(dev, dtype, cfg):
     tol = TOL[dtype]
     assert abs(float(lt[0]) - ref["loss_terms"][0]) <= tol["loss"] * abs(ref["loss_terms"][0])
     assert O.rel_l2(dZ.cpu().numpy(), ref["dZ"].numpy()) <= tol["grad"]
+
+
+def test_env_switch_zero_means_off(dev, monkeypatch):
+    """RENI_NO_PERSIST=0 (and "") must leave the persistent kernels selected: a switch is on when set to anything BUT "" or "0"
+    (reni_plan_create reads it once; reni_path_info reports what is in force)."""
+    spec = O.DecoderSpec(36, "SO2", 128, 5, 3, True, "tanh")
+    seen = {}
+    for val in (None, "0", "", "1"):
+        if val is None:
+            monkeypatch.delenv("RENI_NO_PERSIST", raising=False)
+        else:
+            monkeypatch.setenv("RENI_NO_PERSIST", val)
+        info = make_plan(spec, "bf16").path_info(4, 8192)
+        seen[val] = (info["persistent_kernels"], tuple(info["env_overrides"]))
+    monkeypatch.delenv("RENI_NO_PERSIST", raising=False)
+    assert seen[None] == seen["0"] == seen[""] and seen[None][0] and not seen["1"][0], seen
