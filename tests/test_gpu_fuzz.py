@@ -300,3 +300,48 @@ def test_fuzz_test_loss_and_upstream_gradients(c):
         for k, v in g_ref.items():
             if float(v.abs().max()) > 0:
                 assert O.rel_l2(got_g[k].numpy(), v.numpy()) <= max(tol["grad"], tol_k.get(k, 0.0), 2e-4 if dtype == "f32" else 0.0), (k, tol, tol_k.get(k))
+
+
+def _cases_engine(n=12):
+    rng = np.random.RandomState(20261004)
+    out = []
+    for i in range(n):
+        H = int(rng.choice([128, 128, 256, 64]))
+        out.append(dict(H=H, L=int(rng.randint(1, 6)), eq=str(rng.choice(["SO2", "SO2", "SO3", "None"])), nd=int(rng.choice([2, 9, 36])),
+                        B=int(rng.randint(1, 7)), W=int(rng.choice([16, 32, 64])), dtype="bf16" if rng.rand() < 0.8 else "f32",
+                        loss=str(rng.choice(["mse", "test"])), seed=70000 + i))
+    return out
+
+
+@pytest.mark.parametrize("c", _cases_engine(int(os.environ.get("RENI_FUZZ_ENGINE", "12"))), ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items() if k != "seed"))
+def test_fuzz_fused_training_step_equals_three_calls(c):
+    """reni_train_step_rows (ONE call: gradients, the fused Adam over decoder + latent table, the next batch's prologue staged behind the
+    backward pass) against the three calls it replaces (reni_forward_loss_backward_rows -> reni_adam_step2), on random shapes: every
+    width and depth, one to six images of 128 .. 2 048 directions, both losses, announced and unannounced next batches.  Same kernels in
+    the same order of sums: loss terms of every step, parameters, latents and all four Adam moments must be BIT-EQUAL."""
+    from reni_amd.engine import TrainEngine
+    from reni_amd.models import RENIAutoDecoder
+    from reni_amd.utils import get_directions, get_sineweight
+    dev = torch.device("cuda:0")
+    B, N, W = c["B"], 3 * c["B"], c["W"]
+    D, S = get_directions(W).to(dev), get_sineweight(W).to(dev)
+    P = D.shape[1]
+    T = torch.stack([torch.rand(P, 3, generator=torch.Generator().manual_seed(c["seed"] + 7 * i)) * 2 - 1 for i in range(N)]).to(dev)
+    batches = [torch.arange(B, device=dev) + o for o in (0, B, 2 * B, B, 0)]
+    res = {}
+    for name, kw in (("fused", dict()), ("three_calls", dict(fused_step=False))):
+        torch.manual_seed(c["seed"])
+        m = RENIAutoDecoder(N, c["nd"], c["eq"], c["H"], c["L"], 3, True, "tanh", 30.0, 30.0, False)
+        m.set_compute_dtype(c["dtype"]).to(dev)
+        e = TrainEngine(m, lr=1e-3, loss_kind=c["loss"], alpha=1e-4, beta=1e-2, **kw)
+        terms = []
+        for k, idx in enumerate(batches):
+            nxt = batches[k + 1] if (k + 1 < len(batches) and k != 2) else None   # (step 2 does not announce: the next call runs its own prologue)
+            terms.append(e.step(idx, T[idx], S, D, next_idx=nxt).clone())
+        torch.cuda.synchronize()
+        res[name] = [t.detach().cpu() for t in (torch.stack(terms), m._flat_params(), m.Z.data, e.m_dec, e.v_dec, e.m_lat, e.v_lat)]
+        if name == "fused":
+            assert e._stage is not None, "the fused step did not run"
+    for a, b, what in zip(res["fused"], res["three_calls"], ("terms", "params", "Z", "m_dec", "v_dec", "m_lat", "v_lat")):
+        assert torch.isfinite(a).all(), what
+        assert torch.equal(a, b), (what, float((a - b).abs().max()))
