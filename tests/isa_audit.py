@@ -101,6 +101,20 @@ def audit(text, taken_branch_states=0):
     return res
 
 
+def mfma_functions(text):
+    """-> the set of functions that contain an MFMA at all (what the audits above walk; a function whose every MFMA result is first touched
+    beyond the horizon has no entry in audit()'s result -- k_dw_frag since its builder was pipelined under the MFMAs)."""
+    labels, prog, fnames = parse(text)
+    fk = sorted(fnames)
+    out = set()
+    for k, (_, t) in enumerate(prog):
+        if t.startswith("v_mfma"):
+            j = bisect.bisect_right(fk, k) - 1
+            if j >= 0:
+                out.add(fnames[fk[j]])
+    return out
+
+
 def valu_to_mfma(text, need=2):
     """VALU write of a VGPR -> MFMA reading it as SrcA/SrcB/SrcC needs `need` wait states.  hipcc pads its own MFMAs;
     an asm MFMA without a leading s_nop relies on nothing of the kind sitting in front of it, which is what this

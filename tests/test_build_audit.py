@@ -93,7 +93,7 @@ def test_mfma_results_are_never_read_before_their_write_back():
     kernels, bad = set(), []
     for t in TUS:  # per translation unit: local labels (.LBBn_m) repeat across units
         text = _isa(t)
-        kernels |= {f for f, _ in isa_audit.audit(text)}
+        kernels |= {f for f, _ in isa_audit.audit(text)} | isa_audit.mfma_functions(text)
         bad += isa_audit.violations(text)
         early = isa_audit.valu_to_mfma(text)
         assert not early, f"VALU write within 2 wait states of an MFMA reading it ({t}): " + "; ".join(
