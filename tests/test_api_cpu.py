@@ -383,3 +383,35 @@ def test_bench_contract_line_stays_short_and_last(capsys):
     assert got["step_call"].startswith("reni_train_step_rows_dp") and set(got["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
     sub = json.loads(out[0].split(" ", 2)[2])
     assert out[0].split(" ", 2)[1] == "c4" and sub["roofline"]["kernel"] == roof["kernel"]
+
+
+def test_rocpd_summary_finds_the_training_instance_by_prefix(tmp_path):
+    """profiles/summarize_rocpd.py: the headline / sustained window lines must exist for the CURRENT name of the training instance (it
+    gained a template argument in round 5 and the summary, matching the round-4 name exactly, silently printed no window lines for a
+    whole round) and for the ring kernel."""
+    import sqlite3
+    import subprocess
+    import sys
+    db = tmp_path / "k.db"
+    c = sqlite3.connect(db)
+    c.execute("create table kernels (name text, start integer, end integer)")
+    t = 0
+    for i in range(30):
+        for name, dur in (("void reni::k_reni_train_bf16<128, true, false, false, true, true>(reni::MainArgs)", 1300000 + 1000 * i),
+                          ("void reni::k_reni_l0_ring<128>(reni::MainArgs)", 170000 + 100 * i)):
+            c.execute("insert into kernels values (?, ?, ?)", (name, t, t + dur))
+            t += dur + 5000
+    c.commit(); c.close()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "summarize_rocpd.py"), str(db), str(tmp_path / "o.md"), "20", "5"],
+                         capture_output=True, text=True, check=True).stdout
+    lines = [ln for ln in out.splitlines() if "window" in ln]
+    assert len(lines) == 4, out
+    assert "launches 5..24" in lines[0] and "avg 1314.5 us" in lines[0], lines[0]     # mean of 1305 .. 1324
+    assert "k_reni_l0_ring" in lines[2] and "avg 171.4 us" in lines[2], lines[2]
+
+
+def test_isa_audit_lists_functions_with_mfma_even_without_near_accesses():
+    from tests import isa_audit
+    text = "\n".join(["_Zfoo:", "\tv_mfma_f32_32x32x16_bf16 a[0:15], v[0:3], v[4:7], a[0:15]"] + ["\ts_nop 7"] * 8 + ["\ts_endpgm", "_Zbar:", "\tv_add_f32 v0, v1, v2", "\ts_endpgm"])
+    assert isa_audit.mfma_functions(text) == {"_Zfoo"}
+    assert not any(f == "_Zfoo" for f, _ in isa_audit.audit(text))      # (no access within the horizon: audit() alone does not list it)
